@@ -1,0 +1,572 @@
+#!/usr/bin/env python3
+"""DEV-ONLY: generate `tests/golden/*` by running the REFERENCE itself in the build container.
+
+Usage (build container only; `/root/reference` does not exist on the GPU box):
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+The reference is imported through `oracle/ref_stubs.py` (inert stand-ins for missing packages and a
+restatement of timm 0.4.12 Block/PatchEmbed + torchvision 0.15.1 RandomResizedCrop).  Fixtures are
+data only: inputs, RNG draws (noise tensors, crop boxes) and the reference's outputs.  No reference
+source text is stored.
+"""
+from __future__ import annotations
+
+import contextlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+
+ref_stubs.install()
+_print = print
+import builtins  # noqa: E402
+
+builtins.print = lambda *a, **k: None  # the reference prints from constructors
+import models_mae  # noqa: E402  (reference)
+import engine_pretrain  # noqa: E402  (reference)
+import util.contrast_loss as ref_contrast  # noqa: E402
+import util.lr_sched as ref_lr_sched  # noqa: E402
+import util.misc as ref_misc  # noqa: E402
+import util.pos_embed as ref_pos  # noqa: E402
+from models_mae.MLP import MLP as ref_MLP  # noqa: E402
+
+builtins.print = _print
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+MICRO = dict(dim_model=128, encoder_num_layers=2, encoder_num_heads=2, decoder_embed_dim=64,
+             decoder_num_layers=2, decoder_num_heads=2)
+MICRO_HP = 128
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.array(t)
+
+
+@contextlib.contextmanager
+def quiet():
+    builtins.print = lambda *a, **k: None
+    try:
+        yield
+    finally:
+        builtins.print = _print
+
+
+@contextlib.contextmanager
+def record_rand(store, inject=None):
+    """Record (or replace) every torch.rand draw — the masking noise (MAE_ViT_Shared.py:66)."""
+    orig = torch.rand
+    queue = list(inject) if inject is not None else None
+
+    def rand(*a, **k):
+        r = orig(*a, **k)
+        if queue:
+            r = queue.pop(0).to(r.device).reshape(r.shape)
+        store.append(r.clone())
+        return r
+
+    torch.rand = rand
+    try:
+        yield
+    finally:
+        torch.rand = orig
+
+
+# ------------------------------------------------------------------------------- G1 sincos
+def g_sincos():
+    d = {}
+    for dim, grid in [(128, 4), (64, 4), (768, 4), (512, 4)]:
+        d[f"full_{dim}_{grid}"] = ref_pos.get_2d_sincos_pos_embed(dim, grid, cls_token=True)
+    rng = np.random.RandomState(0)
+    for dim, grid in [(768, 14), (512, 14), (1024, 16), (1280, 16), (1024, 14)]:
+        tab = ref_pos.get_2d_sincos_pos_embed(dim, grid, cls_token=True)
+        idx = rng.randint(0, tab.size, size=4096)
+        d[f"idx_{dim}_{grid}"] = idx
+        d[f"val_{dim}_{grid}"] = tab.reshape(-1)[idx]
+        d[f"sum_{dim}_{grid}"] = np.array([tab.sum(), np.abs(tab).sum(), (tab * np.arange(tab.size).reshape(tab.shape)).sum()])
+    np.savez_compressed(os.path.join(OUT, "sincos.npz"), **d)
+
+
+# ------------------------------------------------------------------------------ G2 masking
+def g_masking(model):
+    d = {}
+    g = torch.Generator().manual_seed(1234)
+    for L in (16, 196, 256):
+        N, D = 8, 4
+        noise = torch.rand(N, L, generator=g)
+        tie_rows = np.zeros(N, dtype=np.int64)
+        noise[5, 3] = noise[5, 1]                       # one exact tie
+        noise[6, : L // 2] = noise[6, L // 2: 2 * (L // 2)]  # many ties
+        noise[7, :] = 0.5                                # all equal
+        tie_rows[5:] = 1
+        x = torch.randn(N, L, D, generator=g)
+        for mr in (0.75, 0.5):
+            rec = []
+            with record_rand(rec, inject=[noise]):
+                xm, mask, ids_restore = model.random_masking(x, mr)
+            assert torch.equal(rec[0], noise)
+            tag = f"L{L}_mr{int(mr * 100)}"
+            d[f"x_masked_{tag}"] = npy(xm)
+            d[f"mask_{tag}"] = npy(mask)
+            d[f"ids_restore_{tag}"] = npy(ids_restore)
+        d[f"noise_L{L}"] = npy(noise)
+        d[f"x_L{L}"] = npy(x)
+        d[f"tie_rows_L{L}"] = tie_rows
+    np.savez_compressed(os.path.join(OUT, "masking.npz"), **d)
+
+
+# --------------------------------------------------------------- G3/G4 patchify and losses
+def g_patch_loss():
+    d = {}
+    g = torch.Generator().manual_seed(7)
+    with quiet():
+        shared = {k: models_mae.MAE_ViT_Baseline.__mro__[1](loss=k) for k in ("mse", "l2", "mae", "l1", "bce")}
+        shared_np = models_mae.MAE_ViT_Baseline.__mro__[1](loss="mse", norm_pix_loss=True)
+    m = shared["mse"]
+    for p, c, s in [(16, 3, 32), (16, 4, 32), (14, 3, 28), (4, 3, 16)]:
+        imgs = torch.randn(2, c, s, s, generator=g)
+        pt = m.patchify(imgs, p, c)
+        d[f"imgs_p{p}c{c}"] = npy(imgs)
+        d[f"patches_p{p}c{c}"] = npy(pt)
+        assert torch.equal(m.unpatchify(pt, p, c), imgs)
+    imgs = torch.randn(3, 3, 32, 32, generator=g)
+    pred = torch.randn(3, 4, 16 * 16 * 3, generator=g)
+    mask = (torch.rand(3, 4, generator=g) > 0.4).float()
+    d["loss_imgs"], d["loss_pred"], d["loss_mask"] = npy(imgs), npy(pred), npy(mask)
+    for k, mod in shared.items():
+        d[f"loss_{k}_masked"] = npy(mod.forward_loss(imgs, pred, mask, 16, 3))
+        d[f"loss_{k}_nomask"] = npy(mod.forward_loss(imgs, pred, None, 16, 3))
+        tgt = torch.randn(3, 4, 20, generator=g)
+        prd = torch.randn(3, 4, 20, generator=g)
+        d[f"raw_t_{k}"], d[f"raw_p_{k}"] = npy(tgt), npy(prd)
+        d[f"loss_{k}_raw"] = npy(mod.forward_loss(tgt, prd))
+    d["target_normpix"] = npy(shared_np.process_target(imgs, 16, 3))
+    d["loss_mse_normpix"] = npy(shared_np.forward_loss(imgs, pred, mask, 16, 3))
+    np.savez_compressed(os.path.join(OUT, "patch_loss.npz"), **d)
+
+
+# ------------------------------------------------------------------------------- G5 ntxent
+def g_ntxent():
+    d = {}
+    g = torch.Generator().manual_seed(11)
+    for bs, D in [(1, 8), (2, 8), (4, 32), (128, 32), (16, 768)]:
+        f1 = torch.randn(bs, D, generator=g) * 2.7
+        f2 = f1 * 0.5 + torch.randn(bs, D, generator=g)
+        f1.requires_grad_(True)
+        f2.requires_grad_(True)
+        loss = ref_contrast.NTXentLoss(bs, 0.5, cos_sim=True)(f1, f2)
+        loss.backward()
+        d[f"f1_{bs}"], d[f"f2_{bs}"], d[f"loss_{bs}"] = npy(f1), npy(f2), npy(loss)
+        d[f"g1_{bs}"], d[f"g2_{bs}"] = npy(f1.grad), npy(f2.grad)
+    np.savez_compressed(os.path.join(OUT, "ntxent.npz"), **d)
+
+
+# ---------------------------------------------------------------------------- G6 predictor
+def g_predictor():
+    d = {}
+    torch.manual_seed(3)
+    mlp = ref_MLP(16, 6, 32)
+    with torch.no_grad():
+        mlp[1].weight.uniform_(0.5, 1.5)
+        mlp[1].bias.uniform_(-0.5, 0.5)
+    for k, v in mlp.state_dict().items():
+        d["sd_" + k] = npy(v)
+    mlp.train()
+    x1 = torch.randn(5, 6, 16, requires_grad=True)
+    x2 = torch.randn(5, 6, 16)
+    y1 = mlp(x1)
+    (y1 ** 2).mean().backward()
+    d["x1"], d["y1"], d["gx1"] = npy(x1), npy(y1), npy(x1.grad)
+    for name, p in mlp.named_parameters():
+        d["g_" + name] = npy(p.grad)
+    d["rm1"], d["rv1"] = npy(mlp[1].running_mean), npy(mlp[1].running_var)
+    y2 = mlp(x2)
+    d["x2"], d["y2"] = npy(x2), npy(y2)
+    d["rm2"], d["rv2"], d["nbt2"] = npy(mlp[1].running_mean), npy(mlp[1].running_var), npy(mlp[1].num_batches_tracked)
+    np.savez_compressed(os.path.join(OUT, "predictor.npz"), **d)
+
+
+# -------------------------------------------------------------------------------- G7 block
+def seeded_state(shapes, seed, scale=0.05):
+    g = torch.Generator().manual_seed(seed)
+    return {k: torch.randn(*shapes[k], generator=g) * scale + (1.0 if k.endswith("norm1.weight") or k.endswith("norm2.weight") else 0.0)
+            for k in sorted(shapes)}
+
+
+def g_block():
+    from functools import partial
+    d = {}
+    meta = {}
+    for tag, (T, D, H, B, store_w) in {"s128": (5, 128, 2, 3, True), "s64": (17, 64, 2, 2, True),
+                                       "b768": (5, 768, 12, 2, False), "b512": (17, 512, 16, 2, False),
+                                       "b1280": (7, 1280, 16, 1, False)}.items():
+        blk = ref_stubs.Block(D, H, 4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+        shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+        seed = 100 + D
+        sd = seeded_state(shapes, seed)
+        blk.load_state_dict(sd)
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(B, T, D, generator=g, requires_grad=True)
+        go = torch.randn(B, T, D, generator=g)
+        y = blk(x)
+        (y * go).sum().backward()
+        meta[tag] = dict(T=T, D=D, H=H, B=B, seed=seed, store_w=store_w)
+        d[f"{tag}_x"], d[f"{tag}_go"], d[f"{tag}_y"], d[f"{tag}_gx"] = npy(x), npy(go), npy(y), npy(x.grad)
+        for name, p in blk.named_parameters():
+            if store_w:
+                d[f"{tag}_w_{name}"] = npy(p)
+                d[f"{tag}_g_{name}"] = npy(p.grad)
+            else:
+                gg = p.grad.double()
+                d[f"{tag}_gn_{name}"] = np.array([gg.pow(2).sum().item(), gg.sum().item()])
+                d[f"{tag}_gs_{name}"] = npy(p.grad.reshape(-1)[:64])
+    np.savez_compressed(os.path.join(OUT, "block.npz"), **d)
+    json.dump(meta, open(os.path.join(OUT, "block_meta.json"), "w"), indent=1)
+
+
+# --------------------------------------------------------------------------------- G8 crop
+def g_crop():
+    d = {}
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randn(2, 2, 64, 64, generator=g)
+    d["imgs64"] = npy(imgs)
+    boxes = [(7, 2, 45, 48), (0, 0, 64, 64), (10, 20, 30, 40), (3, 5, 33, 17), (31, 0, 33, 64)]
+    d["boxes64"] = np.array(boxes)
+    for n, (i, j, h, w) in enumerate(boxes):
+        d[f"out64_{n}"] = npy(torch.nn.functional.interpolate(imgs[..., i:i + h, j:j + w], size=(64, 64), mode="bilinear",
+                                                               align_corners=False, antialias=True))
+    big = torch.randn(1, 3, 224, 224, generator=g)
+    d["seed224"] = np.array([77])
+    big = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(77))
+    boxes = [(12, 40, 131, 150), (100, 3, 97, 120), (0, 0, 193, 224)]
+    d["boxes224"] = np.array(boxes)
+    rng = np.random.RandomState(1)
+    idx = rng.randint(0, big.numel(), size=8192)
+    d["idx224"] = idx
+    for n, (i, j, h, w) in enumerate(boxes):
+        o = torch.nn.functional.interpolate(big[..., i:i + h, j:j + w], size=(224, 224), mode="bilinear",
+                                            align_corners=False, antialias=True)
+        d[f"val224_{n}"] = npy(o.reshape(-1)[idx])
+        d[f"sum224_{n}"] = np.array([o.double().sum().item(), o.double().abs().sum().item()])
+    # RandomResizedCrop box sequence from the CPU RNG (torchvision get_params restated in ref_stubs)
+    seq = []
+    torch.manual_seed(0)
+    for _ in range(16):
+        seq.append(ref_stubs.rrc_get_params(224, 224, (0.25, 0.75)))
+    d["rrc_seed0_224"] = np.array(seq)
+    seq = []
+    torch.manual_seed(123)
+    for _ in range(16):
+        seq.append(ref_stubs.rrc_get_params(64, 64, (0.25, 0.75)))
+    d["rrc_seed123_64"] = np.array(seq)
+    np.savez_compressed(os.path.join(OUT, "crop.npz"), **d)
+
+
+# --------------------------------------------------------------------- G9 full micro model
+SEL = ["cls_token", "mask_token", "patch_embed.proj.bias", "patch_embed.proj.weight", "encoder.0.attn.qkv.weight",
+       "encoder.0.attn.qkv.bias", "encoder.0.norm1.weight", "encoder.1.mlp.fc2.bias", "encoder.1.mlp.fc1.weight",
+       "decoder_embed.weight", "decoder.1.mlp.fc1.weight", "decoder.0.attn.proj.weight", "decoder.1.norm2.bias",
+       "decoder_pred.bias", "decoder_pred.weight", "decoder_norm.weight", "predictor.0.weight", "predictor.1.weight",
+       "predictor.1.bias", "predictor.3.bias", "predictor.3.weight"]
+
+
+def run_variant(cls_name, sd_src, imgs, extra_kw, noise=None, box=None, steps=1, loss="mse", norm_pix=False,
+                reduction="sum"):
+    cls = getattr(models_mae, cls_name) if hasattr(models_mae, cls_name) else models_mae.MAE_ViT_Baseline
+    kw = dict(MICRO, input_size=imgs.shape[-1], patch_size="16", input_channels=imgs.shape[1], loss=loss,
+              norm_pix_loss=norm_pix, **extra_kw)
+    if cls_name != "MAE_ViT_Baseline":
+        kw["ms_decoder_loss_reduction"] = reduction
+    torch.manual_seed(0)
+    with quiet():
+        model = cls(**kw)
+    if sd_src is not None:
+        model.load_state_dict({k: v for k, v in sd_src.items() if k in model.state_dict()}, strict=True)
+    model.train()
+    rec = dict(recon=[], ce=[], cd=[], e=[])
+    orig_fl = model.forward_loss
+
+    def fl(*a, **k):
+        r = orig_fl(*a, **k)
+        rec["recon"].append(r.detach().clone())
+        return r
+
+    model.forward_loss = fl
+    for attr, key in (("_MAE_ViT_MsLdCeCd__forward_loss_cd", "cd"), ("_MAE_ViT_MsLdCd__forward_loss_cd", "cd"),
+                      ("_MAE_ViT_MsLdLeCd__forward_loss_cd", "cd"), ("_MAE_ViT_MsLdLe__forward_loss_e", "e"),
+                      ("_MAE_ViT_MsLdLeCd__forward_loss_e", "e")):
+        if hasattr(model, attr):
+            def mk(orig, key):
+                def f(*a, **k):
+                    r = orig(*a, **k)
+                    rec[key].append(r.detach().clone())
+                    return r
+                return f
+            setattr(model, attr, mk(getattr(model, attr), key))
+    orig_nt = ref_contrast.NTXentLoss.forward
+
+    def nt(self, zi, zj):
+        r = orig_nt(self, zi, zj)
+        rec["ce"].append(r.detach().clone())
+        return r
+
+    ref_contrast.NTXentLoss.forward = nt
+    params = [(n, p) for n, p in model.named_parameters()]
+    decay = [p for n, p in params if p.requires_grad and not (p.ndim == 1 or n.endswith(".bias"))]
+    no_decay = [p for n, p in params if p.requires_grad and (p.ndim == 1 or n.endswith(".bias"))]
+    opt = torch.optim.AdamW([dict(params=no_decay, weight_decay=0.0), dict(params=decay, weight_decay=0.05)],
+                            lr=1e-3, betas=(0.9, 0.95))
+    res = dict(steps=[])
+    noises, boxes = [], []
+    try:
+        for s in range(steps):
+            opt.zero_grad()
+            draws = []
+            if box is not None:
+                bx = box[s]
+                orig_gp = ref_stubs.rrc_get_params
+                ref_stubs.rrc_get_params = lambda *a, **k: bx
+            with record_rand(draws, inject=None if noise is None else noise[s]):
+                out = model(imgs, mask_ratio=0.75, return_embeds=True)
+            if box is not None:
+                ref_stubs.rrc_get_params = orig_gp
+            loss_t = out[0]
+            loss_t.backward()
+            st = dict(loss=loss_t.detach().clone(), pred=out[1].detach().clone(), mask=out[2].detach().clone(),
+                      recon=[r for r in rec["recon"]], ce=list(rec["ce"]), cd=list(rec["cd"]), e=list(rec["e"]),
+                      noise=draws, box=ref_stubs.RandomResizedCrop.last_box,
+                      grads={n: p.grad.detach().clone() for n, p in params if p.grad is not None},
+                      nograd=[n for n, p in params if p.requires_grad and p.grad is None])
+            if cls_name == "MAE_ViT_Baseline":
+                st["enc"], st["dec"] = out[3].detach().clone(), out[4].detach().clone()
+            else:
+                st["enc"] = [t.detach().clone() for t in out[3]]
+                st["dec"] = [t.detach().clone() for t in out[4]]
+            for k in rec:
+                rec[k].clear()
+            opt.step()
+            st["params_after"] = {n: p.detach().clone() for n, p in params}
+            st["buffers_after"] = {n: b.detach().clone() for n, b in model.named_buffers()}
+            res["steps"].append(st)
+    finally:
+        ref_contrast.NTXentLoss.forward = orig_nt
+    res["model"] = model
+    return res
+
+
+def pack_step(d, tag, st, full_sd_keys, level="lite"):
+    d[f"{tag}_loss"] = npy(st["loss"])
+    d[f"{tag}_mask"] = npy(st["mask"])
+    d[f"{tag}_pred_head"] = npy(st["pred"][:, :3, :32])
+    d[f"{tag}_pred_sum"] = np.array([st["pred"].double().sum().item(), st["pred"].double().abs().sum().item()])
+    if level == "full":
+        d[f"{tag}_pred"] = npy(st["pred"])
+    d[f"{tag}_recon"] = np.array([r.item() for r in st["recon"]])
+    for k in ("ce", "cd", "e"):
+        if st[k]:
+            d[f"{tag}_loss_{k}"] = np.array([r.item() for r in st[k]])
+    for n, t in enumerate(st["noise"]):
+        d[f"{tag}_noise{n}"] = npy(t)
+    if st["box"] is not None:
+        d[f"{tag}_box"] = np.array(st["box"])
+    if level == "full":
+        if isinstance(st["enc"], list):
+            d[f"{tag}_enc_orig"], d[f"{tag}_enc_crop"] = npy(st["enc"][0]), npy(st["enc"][1])
+            d[f"{tag}_dec_orig"], d[f"{tag}_dec_crop"] = npy(st["dec"][0]), npy(st["dec"][1])
+        else:
+            d[f"{tag}_enc_orig"], d[f"{tag}_dec_orig"] = npy(st["enc"]), npy(st["dec"])
+    names = sorted(st["grads"])
+    d[f"{tag}_gradnames"] = np.array(names)
+    d[f"{tag}_gradsq"] = np.array([st["grads"][n].double().pow(2).sum().item() for n in names])
+    d[f"{tag}_gradsum"] = np.array([st["grads"][n].double().sum().item() for n in names])
+    d[f"{tag}_nograd"] = np.array(st["nograd"])
+    for n in SEL:
+        if n in st["grads"] and (level == "full" or st["grads"][n].numel() <= 2048):
+            d[f"{tag}_g_{n}"] = npy(st["grads"][n])
+            if st["grads"][n].numel() <= 16384:
+                d[f"{tag}_p_{n}"] = npy(st["params_after"][n])
+    d[f"{tag}_paramsum_after"] = np.array([st["params_after"][n].double().sum().item() for n in names])
+    for n, b in st["buffers_after"].items():
+        d[f"{tag}_buf_{n}"] = npy(b)
+
+
+def g_model_micro():
+    g = torch.Generator().manual_seed(42)
+    imgs = torch.randn(4, 3, 64, 64, generator=g)
+    d = {"imgs": npy(imgs)}
+    # superset state_dict: CeCd
+    res = run_variant("MAE_ViT_MsLdCeCd", None, imgs, dict(predictor_hidden_size=MICRO_HP), steps=2)
+    # state BEFORE training = fresh seeded init; rebuild to store it
+    torch.manual_seed(0)
+    with quiet():
+        fresh = models_mae.MAE_ViT_MsLdCeCd(**MICRO, input_size=64, patch_size="16", predictor_hidden_size=MICRO_HP)
+    sd0 = {k: v.clone() for k, v in fresh.state_dict().items()}
+    for k, v in sd0.items():
+        d["sd_" + k] = npy(v)
+    for s, st in enumerate(res["steps"]):
+        pack_step(d, f"cecd_s{s}", st, sd0, level="full" if s == 0 else "lite")
+    noise = [st["noise"] for st in res["steps"]]
+    box = [st["box"] for st in res["steps"]]
+    for cls_name, extra in [("MAE_ViT_MsLd", {}), ("MAE_ViT_MsLdLe", {}), ("MAE_ViT_MsLdCd", dict(predictor_hidden_size=MICRO_HP)),
+                            ("MAE_ViT_MsLdLeCd", dict(predictor_hidden_size=MICRO_HP))]:
+        r = run_variant(cls_name, sd0, imgs, extra, noise=noise[:1], box=box[:1], steps=1)
+        pack_step(d, cls_name.replace("MAE_ViT_", "").lower() + "_s0", r["steps"][0], sd0)
+    r = run_variant("MAE_ViT_Baseline", sd0, imgs, {}, noise=[noise[0][:1]], steps=1)
+    pack_step(d, "baseline_s0", r["steps"][0], sd0)
+    # loss / option coverage on the headline model (same weights, same draws)
+    for loss in ("l2", "mae", "l1", "bce"):
+        r = run_variant("MAE_ViT_MsLdCeCd", sd0, imgs, dict(predictor_hidden_size=MICRO_HP), noise=noise[:1], box=box[:1], loss=loss)
+        st = r["steps"][0]
+        d[f"cecd_{loss}_loss"] = npy(st["loss"])
+        d[f"cecd_{loss}_recon"] = np.array([x.item() for x in st["recon"]])
+        d[f"cecd_{loss}_loss_cd"] = np.array([x.item() for x in st["cd"]])
+        names = sorted(st["grads"])
+        d[f"cecd_{loss}_gradsq"] = np.array([st["grads"][n].double().pow(2).sum().item() for n in names])
+    r = run_variant("MAE_ViT_MsLdCeCd", sd0, imgs, dict(predictor_hidden_size=MICRO_HP), noise=noise[:1], box=box[:1],
+                    norm_pix=True, reduction="mean")
+    st = r["steps"][0]
+    d["cecd_normpix_mean_loss"] = npy(st["loss"])
+    d["cecd_normpix_mean_recon"] = np.array([x.item() for x in st["recon"]])
+    names = sorted(st["grads"])
+    d["cecd_normpix_mean_gradsq"] = np.array([st["grads"][n].double().pow(2).sum().item() for n in names])
+    # 4-band 128^2 variant (config-4 shape idea at micro width): p=16, C=4, L=64
+    g2 = torch.Generator().manual_seed(43)
+    imgs4 = torch.randn(2, 4, 128, 128, generator=g2)
+    r = run_variant("MAE_ViT_MsLdCeCd", None, imgs4, dict(predictor_hidden_size=MICRO_HP), steps=1)
+    torch.manual_seed(0)
+    with quiet():
+        fresh4 = models_mae.MAE_ViT_MsLdCeCd(**MICRO, input_size=128, input_channels=4, patch_size="16", predictor_hidden_size=MICRO_HP)
+    d4 = {"imgs": npy(imgs4)}
+    for k, v in fresh4.state_dict().items():
+        if k not in sd0 or tuple(v.shape) != tuple(sd0[k].shape) or not torch.equal(v, sd0[k]):
+            d4["sd_" + k] = npy(v)
+    pack_step(d4, "cecd4_s0", r["steps"][0], None)
+    for k in list(d4):
+        if k.startswith("cecd4_s0_p_"):
+            del d4[k]
+    np.savez_compressed(os.path.join(OUT, "model_micro.npz"), **d)
+    np.savez_compressed(os.path.join(OUT, "model_micro_c4.npz"), **d4)
+
+
+# ------------------------------------------------------------- G9b/G10/G11 ViT-B anchors, engine
+def checksum(t):
+    t = t.double()
+    flat = t.reshape(-1)
+    w = torch.arange(flat.numel(), dtype=torch.float64) % 97 + 1
+    return [float(flat.sum()), float(flat.abs().sum()), float((flat * w).sum()), [float(x) for x in flat[:4]]]
+
+
+def g_vitb():
+    out = {}
+    factories = ["mae_vit_base", "mae_vit_base_MsLd", "mae_vit_base_MsLdLe", "mae_vit_base_MsLdCd", "mae_vit_base_MsLdCe",
+                 "mae_vit_base_MsLdLeCd", "mae_vit_base_MsLdCeCd", "mae_vit_large", "mae_vit_huge"]
+    manifest = {}
+    for f in factories:
+        torch.manual_seed(0)
+        with quiet():
+            m = getattr(models_mae, f)(input_size=64, patch_size="16", loss="mse", device="cpu")
+        sd = m.state_dict()
+        manifest[f] = dict(keys=list(sd.keys()), shapes=[list(v.shape) for v in sd.values()],
+                           dtypes=[str(v.dtype) for v in sd.values()],
+                           trainable=int(sum(p.numel() for p in m.parameters() if p.requires_grad)),
+                           param_order=[n for n, _ in m.named_parameters()],
+                           requires_grad=[bool(p.requires_grad) for _, p in m.named_parameters()])
+        if f in ("mae_vit_base", "mae_vit_base_MsLdCeCd"):
+            manifest[f]["checksums"] = {k: checksum(v) for k, v in sd.items() if v.is_floating_point()}
+    torch.manual_seed(0)
+    with quiet():
+        m = models_mae.mae_vit_base_MsLdCeCd(input_size=224, patch_size="16", loss="mse", device="cpu")
+    sd = m.state_dict()
+    manifest["mae_vit_base_MsLdCeCd@224"] = dict(keys=list(sd.keys()), shapes=[list(v.shape) for v in sd.values()],
+                                                 trainable=int(sum(p.numel() for p in m.parameters() if p.requires_grad)))
+    json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"))
+
+    # anchor A: Baseline ViT-B @64^2, N=2 (BASELINE.json configs[0]) through the reference engine
+    d = {}
+    torch.manual_seed(0)
+    with quiet():
+        m = models_mae.mae_vit_base(input_size=64, patch_size="16", loss="mse", device="cpu")
+    x = torch.randn(2, 3, 64, 64)
+    d["cfg1_imgs"] = npy(x)
+    draws = []
+    args = types.SimpleNamespace(accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=1, mask_ratio=0.75,
+                                 local_rank=0, wandb_project=None)
+    decay = [p for n, p in m.named_parameters() if p.requires_grad and not (p.ndim == 1 or n.endswith(".bias"))]
+    no_decay = [p for n, p in m.named_parameters() if p.requires_grad and (p.ndim == 1 or n.endswith(".bias"))]
+    opt = torch.optim.AdamW([dict(params=no_decay, weight_decay=0.0), dict(params=decay, weight_decay=0.05)], lr=1e-3, betas=(0.9, 0.95))
+    with quiet(), record_rand(draws):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            stats = engine_pretrain.train_one_epoch(m, [(x, None)], opt, torch.device("cpu"), 0,
+                                                    ref_misc.NativeScalerWithGradNormCount(), log_writer=None, args=args)
+    d["cfg1_noise"] = npy(draws[0])
+    out["cfg1_stats"] = {k: float(v) for k, v in stats.items()}
+    sd_after = m.state_dict()
+    out["cfg1_after_checksums"] = {k: checksum(sd_after[k]) for k in ("cls_token", "patch_embed.proj.weight", "encoder.0.attn.qkv.weight",
+                                                                      "encoder.11.mlp.fc2.bias", "decoder.7.mlp.fc2.weight", "decoder_pred.bias",
+                                                                      "mask_token", "decoder_norm.weight")}
+    # anchor B: CeCd ViT-B @64^2, N=4
+    torch.manual_seed(0)
+    with quiet():
+        m = models_mae.mae_vit_base_MsLdCeCd(input_size=64, patch_size="16", loss="mse", device="cpu")
+    x = torch.randn(4, 3, 64, 64)
+    d["cecd64_imgs"] = npy(x)
+    res_rec = dict(recon=[], ce=[])
+    ofl = m.forward_loss
+    m.forward_loss = lambda *a, **k: (lambda r: (res_rec["recon"].append(float(r)), r)[1])(ofl(*a, **k))
+    orig_nt = ref_contrast.NTXentLoss.forward
+    ref_contrast.NTXentLoss.forward = lambda self, a, b: (lambda r: (res_rec["ce"].append(float(r)), r)[1])(orig_nt(self, a, b))
+    draws = []
+    with record_rand(draws):
+        o = m(x, return_embeds=True)
+    ref_contrast.NTXentLoss.forward = orig_nt
+    o[0].backward()
+    d["cecd64_noise0"], d["cecd64_noise1"] = npy(draws[0]), npy(draws[1])
+    d["cecd64_pred_head"] = npy(o[1][:, :2, :64])
+    d["cecd64_mask"] = npy(o[2])
+    out["cecd64"] = dict(loss=float(o[0]), recon=res_rec["recon"], ce=res_rec["ce"][0], box=list(ref_stubs.RandomResizedCrop.last_box),
+                         cd=float(o[0]) - sum(res_rec["recon"]) - res_rec["ce"][0],
+                         gradsq={n: float(p.grad.double().pow(2).sum()) for n, p in m.named_parameters() if p.grad is not None},
+                         nograd=[n for n, p in m.named_parameters() if p.requires_grad and p.grad is None])
+    # LR schedule table
+    tab = []
+    for (lr, min_lr, wu, ep) in [(1e-3, 0.0, 40, 400), (1.5e-4, 1e-6, 5, 100), (1e-3, 0.0, 0, 1)]:
+        a = types.SimpleNamespace(lr=lr, min_lr=min_lr, warmup_epochs=wu, epochs=ep)
+        for e in [0.0, 0.5, 1.0, wu * 0.5, float(wu), wu + 0.25, ep * 0.5, ep - 0.5]:
+            grp = [dict(lr=0.0), dict(lr=0.0, lr_scale=0.5)]
+            o2 = types.SimpleNamespace(param_groups=grp)
+            r = ref_lr_sched.adjust_learning_rate(o2, e, a)
+            tab.append([lr, min_lr, wu, ep, e, r, grp[0]["lr"], grp[1]["lr"]])
+    out["lr_table"] = tab
+    json.dump(out, open(os.path.join(OUT, "vitb_anchor.json"), "w"))
+    np.savez_compressed(os.path.join(OUT, "vitb_anchor.npz"), **d)
+
+
+def main():
+    torch.set_num_threads(8)
+    with quiet():
+        tiny = models_mae.MAE_ViT_Baseline(**MICRO, input_size=64, patch_size="16")
+    g_sincos()
+    g_masking(tiny)
+    g_patch_loss()
+    g_ntxent()
+    g_predictor()
+    g_block()
+    g_crop()
+    g_model_micro()
+    g_vitb()
+    for f in sorted(os.listdir(OUT)):
+        _print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
