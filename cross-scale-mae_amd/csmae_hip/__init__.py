@@ -1,0 +1,85 @@
+"""ctypes binding of libcsmae_hip.so (the gfx950 C ABI declared in include/csmae.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel launch fails, the
+product path raises.  PyTorch is used only for device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_void_p
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
+LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsmae_hip.so")
+
+I, L, P, F = c_int, c_longlong, c_void_p, c_float
+_SIGNATURES = {
+    "csmae_gemm": [I, I, I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, I, P],
+    "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
+    "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
+    "csmae_layernorm_fwd": [I, L, I, P, P, P, F, P, P, P, P, P],
+    "csmae_layernorm_bwd": [I, I, L, I, P, P, P, P, P, P, P, P, P, P, P],
+    "csmae_bnrelu_fwd": [I, I, I, I, P, P, P, F, F, P, P, P, P, P, P, P],
+    "csmae_bnrelu_bwd": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "csmae_crop_resize": [L, I, P, P, P, P],
+    "csmae_mask_sort": [L, I, I, P, P, P, P, P, P],
+    "csmae_patch_gather": [I, L, I, I, I, I, I, P, P, P, P, L, P],
+    "csmae_embed_assemble": [L, I, I, P, P, P, P, P, P],
+    "csmae_embed_assemble_bwd": [I, L, I, I, P, P, P, P],
+    "csmae_unshuffle_fwd": [L, I, I, I, P, P, P, P, P, P],
+    "csmae_unshuffle_bwd": [I, L, I, I, I, P, P, P, P, P],
+    "csmae_rows_gather": [I, L, I, P, L, L, L, P, P],
+    "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],
+    "csmae_target_minmax": [I, L, I, I, I, I, P, P, P, P, P],
+    "csmae_recon_loss_fwd": [I, I, L, I, I, I, I, P, P, P, L, P, P, P],
+    "csmae_recon_loss_bwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P, F, P, L, P],
+    "csmae_pair_loss_fwd": [I, L, I, P, L, L, L, P, L, L, L, P, P],
+    "csmae_pair_loss_bwd": [I, I, L, I, P, L, L, L, P, L, L, L, P, F, P, P, P, P],
+    "csmae_ntxent_fwd": [I, I, I, I, P, F, F, P, P, P, P, P, P],
+    "csmae_ntxent_bwd": [I, I, P, P, P, P, F, F, P, P, P],
+    "csmae_latent_grad_finish": [I, L, I, I, P, P, F, P, P],
+    "csmae_loss_finalize": [L, I, P, P, F, P, F, P, F, P, I, P, P],
+    "csmae_adamw": [L, P, P, P, P, P, P, P, P, P, P],
+    "csmae_cast_f32_to_bf16": [L, P, P, P],
+    "csmae_colsum": [I, L, I, P, L, P, P],
+}
+
+_lib = None
+
+
+class CsmaeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CsmaeError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
+                         "the MI355X path has no CPU/eager fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.csmae_last_error.restype = ctypes.c_char_p
+    lib.csmae_abi_version.restype = c_int
+    for name, sig in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = sig
+        fn.restype = c_int
+    if lib.csmae_abi_version() != 1:
+        raise CsmaeError("libcsmae_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise CsmaeError(f"{what} failed ({rc}): {load().csmae_last_error().decode()}")
+
+
+def exported_symbols():
+    return ["csmae_last_error", "csmae_abi_version"] + list(_SIGNATURES)

@@ -1,0 +1,180 @@
+"""Tensor-level launchers for the C ABI (include/csmae.h).  Every function only enqueues HIP kernels on
+torch's current stream; all tensors must live on the GPU, be contiguous in their last dim, and are owned
+by PyTorch.  No function here computes anything with torch ops."""
+from __future__ import annotations
+
+import torch
+
+from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, LOSS_KINDS, check, load
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t: torch.Tensor) -> int:
+    return _DT[t.dtype]
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("csmae_hip ops need GPU tensors: the MI355X path has no CPU fallback")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, splitk=1, st=None):
+    """out[M,N] (+)= A(m,k) B(k,n).  a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b)."""
+    K, M = (a.shape[0], a.shape[1]) if trans_a else (a.shape[1], a.shape[0])
+    Kb, N = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
+    assert K == Kb and out.shape[0] == M and out.shape[1] == N, (a.shape, b.shape, out.shape, trans_a, trans_b)
+    assert a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    check(load().csmae_gemm(dt(a), int(trans_a), int(trans_b), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0),
+                            dt(out), _p(bias), epilogue, _p(aux), aux.stride(0) if aux is not None else 0, _p(resid),
+                            resid.stride(0) if resid is not None else 0, splitk, st if st is not None else stream()), "csmae_gemm")
+    return out
+
+
+def attn_fwd(qkv, out, lse, B, T, H, hd, st=None):
+    check(load().csmae_attn_fwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(lse), st if st is not None else stream()), "csmae_attn_fwd")
+
+
+def attn_bwd(qkv, out, dout, lse, dqkv, B, T, H, hd, st=None):
+    check(load().csmae_attn_bwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), st if st is not None else stream()), "csmae_attn_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, y32=None, eps=1e-6, st=None):
+    M, D = x.shape
+    check(load().csmae_layernorm_fwd(dt(y), M, D, _p(x), _p(gamma), _p(beta), eps, _p(y), _p(y32), _p(mean), _p(rstd),
+                                     st if st is not None else stream()), "csmae_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_out, dgamma, dbeta, dres_in=None, dx_lp=None, st=None):
+    M, D = x.shape
+    lp = dt(dx_lp) if dx_lp is not None else dt(dy)
+    check(load().csmae_layernorm_bwd(dt(dy), lp, M, D, _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres_in), _p(dx_out), _p(dx_lp),
+                                     _p(dgamma), _p(dbeta), st if st is not None else stream()), "csmae_layernorm_bwd")
+
+
+def bnrelu_fwd(u, gamma, beta, r, mean, rstd, N, L, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, st=None):
+    check(load().csmae_bnrelu_fwd(dt(u), N, L, u.shape[1], _p(u), _p(gamma), _p(beta), eps, momentum, _p(r), _p(mean), _p(rstd),
+                                  _p(running_mean), _p(running_var), _p(nbt), st if st is not None else stream()), "csmae_bnrelu_fwd")
+
+
+def bnrelu_bwd(u, dr, gamma, beta, mean, rstd, du, dgamma, dbeta, N, L, st=None):
+    check(load().csmae_bnrelu_bwd(dt(u), N, L, u.shape[1], _p(u), _p(dr), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(du), _p(dgamma),
+                                  _p(dbeta), st if st is not None else stream()), "csmae_bnrelu_bwd")
+
+
+def crop_resize(src, dst, box, st=None):
+    S = src.shape[-1]
+    check(load().csmae_crop_resize(src.numel() // (S * S), S, _p(src), _p(dst), _p(box), st if st is not None else stream()), "csmae_crop_resize")
+
+
+def mask_sort(noise, keep, ids_restore, mask, ids_keep, ids_shuffle=None, st=None):
+    rows, L = noise.shape
+    check(load().csmae_mask_sort(rows, L, keep, _p(noise), _p(ids_restore), _p(mask), _p(ids_keep), _p(ids_shuffle),
+                                 st if st is not None else stream()), "csmae_mask_sort")
+
+
+def patch_gather(img0, img1, ids_keep, out, N, C, S, p, keep, st=None):
+    check(load().csmae_patch_gather(dt(out), out.shape[0], keep, N, C, S, p, _p(img0), _p(img1), _p(ids_keep), _p(out), out.stride(0),
+                                    st if st is not None else stream()), "csmae_patch_gather")
+
+
+def embed_assemble(tok, pos, cls, ids_keep, x, B2, keep, st=None):
+    check(load().csmae_embed_assemble(B2, keep, x.shape[-1], _p(tok), _p(pos), _p(cls), _p(ids_keep), _p(x), st if st is not None else stream()),
+          "csmae_embed_assemble")
+
+
+def embed_assemble_bwd(dx, dtok, dcls, B2, keep, st=None):
+    check(load().csmae_embed_assemble_bwd(dt(dtok), B2, keep, dx.shape[-1], _p(dx), _p(dtok), _p(dcls), st if st is not None else stream()),
+          "csmae_embed_assemble_bwd")
+
+
+def unshuffle_fwd(z, mask_token, dpos, ids_restore, xd, B2, L, keep, st=None):
+    check(load().csmae_unshuffle_fwd(B2, L, keep, xd.shape[-1], _p(z), _p(mask_token), _p(dpos), _p(ids_restore), _p(xd),
+                                     st if st is not None else stream()), "csmae_unshuffle_fwd")
+
+
+def unshuffle_bwd(dxd, ids_restore, dz, dmask_token, B2, L, keep, st=None):
+    check(load().csmae_unshuffle_bwd(dt(dz), B2, L, keep, dxd.shape[-1], _p(dxd), _p(ids_restore), _p(dz), _p(dmask_token),
+                                     st if st is not None else stream()), "csmae_unshuffle_bwd")
+
+
+def rows_gather(src, dst, group, gstride, off, st=None):
+    check(load().csmae_rows_gather(dt(dst), dst.shape[0], dst.shape[1], _p(src), group, gstride, off, _p(dst), st if st is not None else stream()),
+          "csmae_rows_gather")
+
+
+def rows_scatter_add(src, dst, group, gstride, off, scale=1.0, st=None):
+    check(load().csmae_rows_scatter_add(dt(src), src.shape[0], src.shape[1], _p(src), scale, group, gstride, off, _p(dst),
+                                        st if st is not None else stream()), "csmae_rows_scatter_add")
+
+
+def target_minmax(img0, img1, scratch, out, B2, N, C, S, p, norm_pix, st=None):
+    check(load().csmae_target_minmax(int(norm_pix), B2, N, C, S, p, _p(img0), _p(img1), _p(scratch), _p(out), st if st is not None else stream()),
+          "csmae_target_minmax")
+
+
+def recon_loss_fwd(kind, norm_pix, img0, img1, pred, minmax, rowloss, B2, N, C, S, p, st=None):
+    check(load().csmae_recon_loss_fwd(LOSS_KINDS[kind], int(norm_pix), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0), _p(minmax),
+                                      _p(rowloss), st if st is not None else stream()), "csmae_recon_loss_fwd")
+
+
+def recon_loss_bwd(kind, norm_pix, img0, img1, pred, minmax, mask, losses, gout, vscale, dpred, B2, N, C, S, p, st=None):
+    check(load().csmae_recon_loss_bwd(LOSS_KINDS[kind], int(norm_pix), dt(dpred), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0),
+                                      _p(minmax), _p(mask), _p(losses), _p(gout), vscale, _p(dpred), dpred.stride(0),
+                                      st if st is not None else stream()), "csmae_recon_loss_bwd")
+
+
+def pair_loss_fwd(kind, rows, D, a, aview, t, tview, partial, st=None):
+    check(load().csmae_pair_loss_fwd(LOSS_KINDS[kind], rows, D, _p(a), *aview, _p(t), *tview, _p(partial), st if st is not None else stream()),
+          "csmae_pair_loss_fwd")
+
+
+def pair_loss_bwd(kind, rows, D, a, aview, t, tview, gout, coef, da_lp=None, da_acc=None, dt_acc=None, lp_dtype=F32, st=None):
+    lp = dt(da_lp) if da_lp is not None else lp_dtype
+    check(load().csmae_pair_loss_bwd(LOSS_KINDS[kind], lp, rows, D, _p(a), *aview, _p(t), *tview, _p(gout), coef, _p(da_lp), _p(da_acc), _p(dt_acc),
+                                     st if st is not None else stream()), "csmae_pair_loss_bwd")
+
+
+def ntxent_fwd(latent, z, inv_norm, E, neg, rowloss, N, Te, keep, tau=0.5, eps=1e-8, st=None):
+    check(load().csmae_ntxent_fwd(N, Te, keep, latent.shape[-1], _p(latent), tau, eps, _p(z), _p(inv_norm), _p(E), _p(neg), _p(rowloss),
+                                  st if st is not None else stream()), "csmae_ntxent_fwd")
+
+
+def ntxent_bwd(z, inv_norm, E, neg, gout, dpool, N, tau=0.5, eps=1e-8, st=None):
+    check(load().csmae_ntxent_bwd(N, z.shape[-1], _p(z), _p(inv_norm), _p(E), _p(neg), tau, eps, _p(gout), _p(dpool), st if st is not None else stream()),
+          "csmae_ntxent_bwd")
+
+
+def latent_grad_finish(dlat, dpool, inv_keep, dlat_lp, B2, Te, st=None):
+    lp = dt(dlat_lp) if dlat_lp is not None else F32
+    check(load().csmae_latent_grad_finish(lp, B2, Te, dlat.shape[-1], _p(dlat), _p(dpool), inv_keep, _p(dlat_lp), st if st is not None else stream()),
+          "csmae_latent_grad_finish")
+
+
+def loss_finalize(per_view, views, rowloss, mask, recon_scale, losses, cd_partial=None, cd_scale=0.0, e_partial=None, e_scale=0.0,
+                  ce_rowloss=None, ce_rows=0, st=None):
+    check(load().csmae_loss_finalize(per_view, views, _p(rowloss), _p(mask), recon_scale, _p(cd_partial), cd_scale, _p(e_partial), e_scale,
+                                     _p(ce_rowloss), ce_rows, _p(losses), st if st is not None else stream()), "csmae_loss_finalize")
+
+
+def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, hyper, p_lp=None, st=None):
+    check(load().csmae_adamw(tile_off.numel(), _p(tile_off), _p(tile_cnt), _p(tile_wd), _p(p), _p(g), _p(m), _p(v), _p(hyper), _p(p_lp),
+                             st if st is not None else stream()), "csmae_adamw")
+
+
+def cast_bf16(src, dst, st=None):
+    check(load().csmae_cast_f32_to_bf16(src.numel(), _p(src), _p(dst), st if st is not None else stream()), "csmae_cast_f32_to_bf16")
+
+
+def colsum(x, out, st=None):
+    check(load().csmae_colsum(dt(x), x.shape[0], x.shape[1], _p(x), x.stride(0), _p(out), st if st is not None else stream()), "csmae_colsum")
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,402 @@
+// Softmax attention of the timm Block: per (sample, head) independent problems with
+// tiny sequences (T = 50/65 encoder, 197/257 decoder; head_dim 64/80 and 32), so one workgroup owns one
+// (sample, head) and keeps the whole K and V of that head in LDS: single-pass softmax, no online rescaling.
+//
+// bf16 path: everything is computed TRANSPOSED (S^T = K Q^T) so that after the MFMA each lane owns ONE query
+// column: softmax row statistics are lane-local plus two cross-lane-group shuffles, and the probabilities sit
+// in exactly the register layout the next MFMA wants as its B operand (no LDS round trip for P).  V^T / K^T /
+// Q^T / dO^T operands come straight out of row-major LDS images through ds_read_b64_tr_b16.
+// Backward = a query-row pass (dQ) and a key-column pass (dK, dV) that mirror the forward; S and dP are
+// recomputed in each pass (attention is 3.7 % of the step's FLOPs; this avoids cross-wave reductions).
+// fp32 path: exact fp32 (parity mode), one thread per query row / key column.
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// ------------------------------------------------------------------------------------------ bf16 helpers
+template <int HD> struct AttnLds { static constexpr int STRIDE = (HD + 8) * 2; };  // bytes per row (16-B multiple)
+
+// stage rows [0,TP) of one head's matrix (column offset `col0` inside a [B*T, ld] tensor) into LDS, zero padded
+template <int HD, int TP>
+__device__ __forceinline__ void stage_head(char* dst, const bf16_t* src, long long row0, int ld, int col0, int T, int hd) {
+  constexpr int CH = HD / 8;
+  for (int e = threadIdx.x; e < TP * CH; e += blockDim.x) {
+    int r = e / CH, c = e - r * CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < T && c * 8 < hd) v = *reinterpret_cast<const uint4*>(src + (row0 + r) * ld + col0 + c * 8);
+    *reinterpret_cast<uint4*>(dst + r * AttnLds<HD>::STRIDE + c * 16) = v;
+  }
+}
+
+// K-contiguous fragment (lane (t,g): row = row0 + t, elements d = ks*32 + 8g .. +8)
+template <int HD>
+__device__ __forceinline__ s8_t frag_rows(const char* img, int row0, int ks, int t, int g) {
+  return *reinterpret_cast<const s8_t*>(img + (row0 + t) * AttnLds<HD>::STRIDE + (ks * 32 + 8 * g) * 2);
+}
+// transposed fragment via tr-read: A operand with i = column (c0 + t) and k = rows {r0+4g+j, r0+16+4g+j}
+template <int HD>
+__device__ __forceinline__ s8_t frag_cols_tr(const char* img, int r0, int c0, int t, int g) {
+  const char* p = img + (r0 + 4 * g + (t >> 2)) * AttnLds<HD>::STRIDE + (c0 + (t & 3) * 4) * 2;
+  s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, p));
+  s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, p + 16 * AttnLds<HD>::STRIDE));
+  return s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ s8_t pack_pair(f4_t a, f4_t b) {
+  unsigned u0 = pack2bf(a[0], a[1]), u1 = pack2bf(a[2], a[3]), u2 = pack2bf(b[0], b[1]), u3 = pack2bf(b[2], b[3]);
+  uint4 u = make_uint4(u0, u1, u2, u3);
+  return __builtin_bit_cast(s8_t, u);
+}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------ bf16 forward
+template <int HD, int NKF>
+__global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                     float* __restrict__ lse, int T, int H, int D, int hd, float scale) {
+  constexpr int TP = NKF * 16, KS = HD / 32, DF = HD / 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TP * AttnLds<HD>::STRIDE];
+  char* Ks = smem;
+  char* Vs = smem + TP * AttnLds<HD>::STRIDE;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long row0 = (long long)b * T;
+  const int ld = 3 * D;
+  stage_head<HD, TP>(Ks, qkv, row0, ld, D + h * hd, T, hd);
+  stage_head<HD, TP>(Vs, qkv, row0, ld, 2 * D + h * hd, T, hd);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  const float c2 = scale * LOG2E;
+  const int nqb = (T + 15) >> 4;
+  for (int qb = w; qb < nqb; qb += 4) {
+    const int q = qb * 16 + t;
+    s8_t fq[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      int d = ks * 32 + 8 * g;
+      if (q < T && d < hd) v = *reinterpret_cast<const uint4*>(qkv + (row0 + q) * ld + h * hd + d);
+      fq[ks] = __builtin_bit_cast(s8_t, v);
+    }
+    f4_t s[NKF];
+    float m = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) {
+      f4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a = MFMA16(frag_rows<HD>(Ks, f * 16, ks, t, g), fq[ks], a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = f * 16 + 4 * g + r;
+        a[r] = key < T ? a[r] * c2 : -INFINITY;
+        m = fmaxf(m, a[r]);
+      }
+      s[f] = a;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int f = 0; f < NKF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float p = exp2f(s[f][r] - m); s[f][r] = p; l += p; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    s8_t fp[NKF / 2];
+#pragma unroll
+    for (int s2 = 0; s2 < NKF / 2; ++s2) fp[s2] = pack_pair(s[2 * s2], s[2 * s2 + 1]);
+#pragma unroll
+    for (int df = 0; df < DF; ++df) {
+      f4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < NKF / 2; ++s2) o = MFMA16(frag_cols_tr<HD>(Vs, 32 * s2, df * 16, t, g), fp[s2], o);
+      int d = df * 16 + 4 * g;
+      if (q < T && d < hd) st4<bf16_t>(out + (row0 + q) * D + h * hd + d, o * inv);
+    }
+    if (g == 0 && q < T) lse[((long long)b * H + h) * T + q] = (m + log2f(l)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ bf16 backward
+template <int HD, int NKF>
+__global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                     bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale) {
+  constexpr int TP = NKF * 16, KS = HD / 32, DF = HD / 16, IMG = TP * AttnLds<HD>::STRIDE;
+  __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 2 * TP * 4];
+  char* Qs = smem; char* Ks = smem + IMG; char* Vs = smem + 2 * IMG; char* Gs = smem + 3 * IMG;  // Gs = dO
+  float* lse2 = reinterpret_cast<float*>(smem + 4 * IMG);  // log2-domain LSE, +inf on padded rows
+  float* dl = lse2 + TP;                                     // D_i = sum_d dO_i . O_i
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long row0 = (long long)b * T;
+  const int ld = 3 * D;
+  stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);
+  stage_head<HD, TP>(Ks, qkv, row0, ld, D + h * hd, T, hd);
+  stage_head<HD, TP>(Vs, qkv, row0, ld, 2 * D + h * hd, T, hd);
+  stage_head<HD, TP>(Gs, dout, row0, D, h * hd, T, hd);
+  for (int r = threadIdx.x; r < TP; r += blockDim.x) {
+    float acc = 0.f, l2 = INFINITY;
+    if (r < T) {
+      l2 = lse[((long long)b * H + h) * T + r] * LOG2E;
+      const bf16_t* o = out + (row0 + r) * D + h * hd;
+      const bf16_t* gg = dout + (row0 + r) * D + h * hd;
+      for (int d = 0; d < hd; d += 4) { f4_t a = ld4<bf16_t>(o + d), c = ld4<bf16_t>(gg + d); acc += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3]; }
+    }
+    lse2[r] = l2; dl[r] = acc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  const float c2 = scale * LOG2E;
+  const int nblk = (T + 15) >> 4;
+  // ---- pass 1: query rows -> dQ.  lane owns query column q; registers run over keys.
+  for (int qb = w; qb < nblk; qb += 4) {
+    const int q = qb * 16 + t;
+    s8_t fq[KS], fg[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { fq[ks] = frag_rows<HD>(Qs, qb * 16, ks, t, g); fg[ks] = frag_rows<HD>(Gs, qb * 16, ks, t, g); }
+    const float my_l2 = lse2[q], my_dl = dl[q];
+    s8_t fds[NKF / 2];
+    f4_t prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) {
+      f4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a = MFMA16(frag_rows<HD>(Ks, f * 16, ks, t, g), fq[ks], a);
+        dp = MFMA16(frag_rows<HD>(Vs, f * 16, ks, t, g), fg[ks], dp);
+      }
+      f4_t ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = f * 16 + 4 * g + r;
+        float p = key < T ? exp2f(a[r] * c2 - my_l2) : 0.f;
+        ds[r] = p * (dp[r] - my_dl) * scale;
+      }
+      if (f & 1) fds[f >> 1] = pack_pair(prev, ds); else prev = ds;
+    }
+#pragma unroll
+    for (int df = 0; df < DF; ++df) {
+      f4_t o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < NKF / 2; ++s2) o = MFMA16(frag_cols_tr<HD>(Ks, 32 * s2, df * 16, t, g), fds[s2], o);
+      int d = df * 16 + 4 * g;
+      if (q < T && d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, o);
+    }
+  }
+  // ---- pass 2: key columns -> dK, dV.  lane owns key column; registers run over queries.
+  for (int kb = w; kb < nblk; kb += 4) {
+    const int key = kb * 16 + t;
+    s8_t fk[KS], fv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { fk[ks] = frag_rows<HD>(Ks, kb * 16, ks, t, g); fv[ks] = frag_rows<HD>(Vs, kb * 16, ks, t, g); }
+    s8_t fp[NKF / 2], fds[NKF / 2];
+    f4_t prev_p = {0.f, 0.f, 0.f, 0.f}, prev_ds = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) {
+      f4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a = MFMA16(frag_rows<HD>(Qs, f * 16, ks, t, g), fk[ks], a);
+        dp = MFMA16(frag_rows<HD>(Gs, f * 16, ks, t, g), fv[ks], dp);
+      }
+      f4_t l4 = *reinterpret_cast<const f4_t*>(lse2 + f * 16 + 4 * g);
+      f4_t d4 = *reinterpret_cast<const f4_t*>(dl + f * 16 + 4 * g);
+      f4_t p, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = exp2f(a[r] * c2 - l4[r]);  // padded queries have lse2 = +inf -> p = 0
+        ds[r] = p[r] * (dp[r] - d4[r]) * scale;
+      }
+      if (f & 1) { fp[f >> 1] = pack_pair(prev_p, p); fds[f >> 1] = pack_pair(prev_ds, ds); } else { prev_p = p; prev_ds = ds; }
+    }
+#pragma unroll
+    for (int df = 0; df < DF; ++df) {
+      f4_t ok = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < NKF / 2; ++s2) {
+        ok = MFMA16(frag_cols_tr<HD>(Qs, 32 * s2, df * 16, t, g), fds[s2], ok);
+        ov = MFMA16(frag_cols_tr<HD>(Gs, 32 * s2, df * 16, t, g), fp[s2], ov);
+      }
+      int d = df * 16 + 4 * g;
+      if (key < T && d < hd) {
+        st4<bf16_t>(dqkv + (row0 + key) * ld + D + h * hd + d, ok);
+        st4<bf16_t>(dqkv + (row0 + key) * ld + 2 * D + h * hd + d, ov);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ fp32 (parity mode)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qkv, float* __restrict__ out,
+                                                    float* __restrict__ lse, int T, int H, int D, int hd, float scale) {
+  extern __shared__ float sm[];
+  const int S = hd + 1;
+  float* Ks = sm; float* Vs = sm + T * S;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long row0 = (long long)b * T;
+  const int ld = 3 * D;
+  for (int e = threadIdx.x; e < T * hd; e += blockDim.x) {
+    int r = e / hd, d = e - r * hd;
+    Ks[r * S + d] = qkv[(row0 + r) * ld + D + h * hd + d];
+    Vs[r * S + d] = qkv[(row0 + r) * ld + 2 * D + h * hd + d];
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < T; q += blockDim.x) {
+    float qr[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qr[d] = d < hd ? qkv[(row0 + q) * ld + h * hd + d] * scale : 0.f;
+    float m = -INFINITY;
+    for (int j = 0; j < T; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) if (d < hd) s = fmaf(qr[d], Ks[j * S + d], s);
+      m = fmaxf(m, s);
+    }
+    float l = 0.f, o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    for (int j = 0; j < T; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) if (d < hd) s = fmaf(qr[d], Ks[j * S + d], s);
+      float p = expf(s - m);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) if (d < hd) o[d] = fmaf(p, Vs[j * S + d], o[d]);
+    }
+    float inv = 1.0f / l;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) if (d < hd) out[(row0 + q) * D + h * hd + d] = o[d] * inv;
+    lse[((long long)b * H + h) * T + q] = m + logf(l);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                    const float* __restrict__ dout, const float* __restrict__ lse,
+                                                    float* __restrict__ dqkv, int T, int H, int D, int hd, float scale) {
+  extern __shared__ float sm[];
+  const int S = hd + 1;
+  float* Qs = sm; float* Ks = Qs + T * S; float* Vs = Ks + T * S; float* Gs = Vs + T * S;
+  float* ls = Gs + T * S; float* dl = ls + T;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long row0 = (long long)b * T;
+  const int ld = 3 * D;
+  for (int e = threadIdx.x; e < T * hd; e += blockDim.x) {
+    int r = e / hd, d = e - r * hd;
+    Qs[r * S + d] = qkv[(row0 + r) * ld + h * hd + d];
+    Ks[r * S + d] = qkv[(row0 + r) * ld + D + h * hd + d];
+    Vs[r * S + d] = qkv[(row0 + r) * ld + 2 * D + h * hd + d];
+    Gs[r * S + d] = dout[(row0 + r) * D + h * hd + d];
+  }
+  for (int r = threadIdx.x; r < T; r += blockDim.x) {
+    float acc = 0.f;
+    for (int d = 0; d < hd; ++d) acc = fmaf(out[(row0 + r) * D + h * hd + d], dout[(row0 + r) * D + h * hd + d], acc);
+    dl[r] = acc; ls[r] = lse[((long long)b * H + h) * T + r];
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < T; q += blockDim.x) {  // dQ
+    float dq[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+    const float lq = ls[q], dlq = dl[q];
+    for (int j = 0; j < T; ++j) {
+      float s = 0.f, dp = 0.f;
+      for (int d = 0; d < hd; ++d) { s = fmaf(Qs[q * S + d], Ks[j * S + d], s); dp = fmaf(Gs[q * S + d], Vs[j * S + d], dp); }
+      float ds = expf(s * scale - lq) * (dp - dlq) * scale;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) if (d < hd) dq[d] = fmaf(ds, Ks[j * S + d], dq[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) if (d < hd) dqkv[(row0 + q) * ld + h * hd + d] = dq[d];
+  }
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {  // dK, dV
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < T; ++i) {
+      float s = 0.f, dp = 0.f;
+      for (int d = 0; d < hd; ++d) { s = fmaf(Qs[i * S + d], Ks[j * S + d], s); dp = fmaf(Gs[i * S + d], Vs[j * S + d], dp); }
+      float p = expf(s * scale - ls[i]);
+      float ds = p * (dp - dl[i]) * scale;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) if (d < hd) { dk[d] = fmaf(ds, Qs[i * S + d], dk[d]); dv[d] = fmaf(p, Gs[i * S + d], dv[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) if (d < hd) {
+      dqkv[(row0 + j) * ld + D + h * hd + d] = dk[d];
+      dqkv[(row0 + j) * ld + 2 * D + h * hd + d] = dv[d];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dispatch
+template <int HD, int NKF>
+static void launch_fwd_bf16(int BH, const void* qkv, void* out, float* lse, int T, int H, int D, int hd, float scale, hipStream_t st) {
+  hipLaunchKernelGGL((attn_fwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, D, hd, scale);
+}
+template <int HD, int NKF>
+static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int T, int H, int D, int hd, float scale, hipStream_t st) {
+  hipLaunchKernelGGL((attn_bwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
+}
+
+// (head_dim bucket, key-fragment count) combinations whose LDS images fit 160 KiB in the backward kernel
+#define NKF_SMALL(HDV, CALL)                                 \
+  if (T <= 32) { CALL(HDV, 2); }                             \
+  else if (T <= 64) { CALL(HDV, 4); }                        \
+  else if (T <= 96) { CALL(HDV, 6); }
+#define DISPATCH_BF16(CALL)                                                            \
+  if (hd <= 32) { NKF_SMALL(32, CALL) else if (T <= 224) { CALL(32, 14); } else { CALL(32, 18); } } \
+  else if (hd <= 64) { NKF_SMALL(64, CALL) else { CALL(64, 14); } }                    \
+  else { NKF_SMALL(96, CALL) }
+
+static int check_common(const char* who, long long B, int T, int H, int D, int hd) {
+  CSMAE_REQUIRE(B > 0 && T > 0 && H > 0 && hd > 0 && D == H * hd, "%s: bad geometry B=%lld T=%d H=%d D=%d hd=%d", who, B, T, H, D, hd);
+  CSMAE_REQUIRE(T <= 288, "%s: sequence length %d > 288 is outside the hot-path scope (SURVEY §5: tokens per view <= 257)", who, T);
+  CSMAE_REQUIRE(hd <= 96 && hd % 8 == 0, "%s: head_dim %d unsupported (need multiple of 8, <= 96)", who, hd);
+  CSMAE_REQUIRE(hd <= 32 || (hd <= 64 && T <= 224) || T <= 96, "%s: (T=%d, head_dim=%d) exceeds the LDS-resident design (hd<=32: T<=288, hd<=64: T<=224, hd<=96: T<=96)", who, T, hd);
+  return CSMAE_OK;
+}
+
+extern "C" int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* stream) {
+  const int D = H * hd;
+  int rc = check_common("csmae_attn_fwd", B, T, H, D, hd);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int BH = (int)(B * H);
+  if (dtype == CSMAE_BF16) {
+#define CALLF(HDV, NK) launch_fwd_bf16<HDV, NK>(BH, qkv, out, lse, T, H, D, hd, scale, st)
+    DISPATCH_BF16(CALLF)
+#undef CALLF
+  } else if (dtype == CSMAE_F32) {
+    size_t sh = (size_t)2 * T * (hd + 1) * sizeof(float);
+    CSMAE_REQUIRE(sh <= 160 * 1024, "csmae_attn_fwd(f32): T*hd too large for LDS");
+    if (hd <= 32) hipLaunchKernelGGL((attn_fwd_f32<32>), dim3(BH), dim3(256), sh, st, (const float*)qkv, (float*)out, lse, T, H, D, hd, scale);
+    else if (hd <= 64) hipLaunchKernelGGL((attn_fwd_f32<64>), dim3(BH), dim3(256), sh, st, (const float*)qkv, (float*)out, lse, T, H, D, hd, scale);
+    else hipLaunchKernelGGL((attn_fwd_f32<96>), dim3(BH), dim3(256), sh, st, (const float*)qkv, (float*)out, lse, T, H, D, hd, scale);
+  } else { csmae_set_error("csmae_attn_fwd: unsupported dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_attn_fwd");
+}
+
+extern "C" int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
+                              const float* lse, void* dqkv, void* stream) {
+  const int D = H * hd;
+  int rc = check_common("csmae_attn_bwd", B, T, H, D, hd);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int BH = (int)(B * H);
+  if (dtype == CSMAE_BF16) {
+#define CALLB(HDV, NK) launch_bwd_bf16<HDV, NK>(BH, qkv, out, dout, lse, dqkv, T, H, D, hd, scale, st)
+    DISPATCH_BF16(CALLB)
+#undef CALLB
+  } else if (dtype == CSMAE_F32) {
+    size_t sh = ((size_t)4 * T * (hd + 1) + 2 * T) * sizeof(float);
+    CSMAE_REQUIRE(sh <= 160 * 1024, "csmae_attn_bwd(f32): T*hd too large for LDS");
+    if (hd <= 32) hipLaunchKernelGGL((attn_bwd_f32<32>), dim3(BH), dim3(256), sh, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, T, H, D, hd, scale);
+    else if (hd <= 64) hipLaunchKernelGGL((attn_bwd_f32<64>), dim3(BH), dim3(256), sh, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, T, H, D, hd, scale);
+    else hipLaunchKernelGGL((attn_bwd_f32<96>), dim3(BH), dim3(256), sh, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, T, H, D, hd, scale);
+  } else { csmae_set_error("csmae_attn_bwd: unsupported dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_attn_bwd");
+}

@@ -1,0 +1,101 @@
+// Shared device/host helpers for libcsmae_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+
+#define CSMAE_F32 0
+#define CSMAE_BF16 1
+
+#define CSMAE_OK 0
+#define CSMAE_ERR_ARG -1
+#define CSMAE_ERR_LAUNCH -2
+#define CSMAE_ERR_UNSUPPORTED -3
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef short s8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---- error plumbing (thread-local message; see include/csmae.h csmae_last_error)
+void csmae_set_error(const char* fmt, ...);
+int csmae_check_launch(const char* what);
+#define CSMAE_REQUIRE(cond, ...)                     \
+  do {                                               \
+    if (!(cond)) {                                   \
+      csmae_set_error(__VA_ARGS__);                  \
+      return CSMAE_ERR_ARG;                          \
+    }                                                \
+  } while (0)
+
+// ---- scalar conversions (round-to-nearest-even, NaN preserved)
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p);
+template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_as_f32<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st_from_f32(T* p, float v);
+template <> __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 4 consecutive elements (pointer must be 4-element aligned)
+template <typename T> __device__ __forceinline__ f4_t ld4(const T* p);
+template <> __device__ __forceinline__ f4_t ld4<float>(const float* p) { return *reinterpret_cast<const f4_t*>(p); }
+template <> __device__ __forceinline__ f4_t ld4<bf16_t>(const bf16_t* p) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  f4_t r = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  return r;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f4_t v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f4_t v) { *reinterpret_cast<f4_t*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f4_t v) {
+  uint2 u; u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <typename T> __device__ __forceinline__ f4_t round4(f4_t v);
+template <> __device__ __forceinline__ f4_t round4<float>(f4_t v) { return v; }
+template <> __device__ __forceinline__ f4_t round4<bf16_t>(f4_t v) {
+  return f4_t{bf2f(f2bf(v[0])), bf2f(f2bf(v[1])), bf2f(f2bf(v[2])), bf2f(f2bf(v[3]))};
+}
+
+// ---- wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block reduction of one float over blockDim.x threads (<=1024); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats */) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { float s = 0; for (int i = 0; i < nw; ++i) s += smem[i]; smem[16] = s; }
+  __syncthreads();
+  return smem[16];
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,249 @@
+// LayerNorm (timm Block norm1/norm2, decoder_norm; eps 1e-6 — MAE_ViT_Baseline.py:43-45) and the predictor's
+// BatchNorm1d-over-token-positions + ReLU (models_mae/MLP.py:4-10).  All HBM-bound: one wave per LayerNorm row
+// (wave-shuffle reductions, 16-B accesses), one workgroup per BatchNorm channel.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ LayerNorm forward
+template <typename TO, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, TO* __restrict__ y, float* __restrict__ y32,
+                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = D >> 2;
+  f4_t v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + i * 64;
+    v[i] = c < nv ? *reinterpret_cast<const f4_t*>(x + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + i * 64;
+    if (c < nv) { f4_t d = v[i] - mu; q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]; }
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + i * 64;
+    if (c < nv) {
+      f4_t gm = *reinterpret_cast<const f4_t*>(gamma + c * 4), bt = *reinterpret_cast<const f4_t*>(beta + c * 4);
+      f4_t o = (v[i] - mu) * rs * gm + bt;
+      st4<TO>(y + row * D + c * 4, o);
+      if (y32) *reinterpret_cast<f4_t*>(y32 + row * D + c * 4) = o;
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm backward
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ;  dres_out = dres_in + dx ;  dgamma += dy*xhat ; dbeta += dy
+template <typename TDY, typename TLP, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const TDY* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres_in,
+                                                     float* __restrict__ dx_out, TLP* __restrict__ dx_lp,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[4 * 64 * 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  f4_t gm[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + i * 64;
+    gm[i] = c < nv ? *reinterpret_cast<const f4_t*>(gamma + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+    ag[i] = f4_t{0.f, 0.f, 0.f, 0.f}; ab[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long long row = (long long)blockIdx.x * 4 + w; row < M; row += (long long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f4_t g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + i * 64;
+      if (c < nv) {
+        f4_t d = ld4<TDY>(dy + row * D + c * 4);
+        xh[i] = (*reinterpret_cast<const f4_t*>(x + row * D + c * 4) - mu) * rs;
+        ag[i] += d * xh[i]; ab[i] += d;
+        g[i] = d * gm[i];
+        s1 += g[i][0] + g[i][1] + g[i][2] + g[i][3];
+        f4_t t = g[i] * xh[i];
+        s2 += t[0] + t[1] + t[2] + t[3];
+      }
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + i * 64;
+      if (c < nv) {
+        f4_t dx = (g[i] - s1 - xh[i] * s2) * rs;
+        if (dres_in) dx += *reinterpret_cast<const f4_t*>(dres_in + row * D + c * 4);
+        *reinterpret_cast<f4_t*>(dx_out + row * D + c * 4) = dx;
+        if (dx_lp) st4<TLP>(dx_lp + row * D + c * 4, dx);
+      }
+    }
+  }
+  if (!dgamma) return;
+  // fold the 4 waves' column partials, then one atomic per column per block
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int c = lane + i * 64;
+    __syncthreads();
+    *reinterpret_cast<f4_t*>(red + (w * 64 + lane) * 4) = ag[i];
+    __syncthreads();
+    if (w == 0 && c < nv) {
+      f4_t s = *reinterpret_cast<f4_t*>(red + lane * 4) + *reinterpret_cast<f4_t*>(red + (64 + lane) * 4) +
+               *reinterpret_cast<f4_t*>(red + (128 + lane) * 4) + *reinterpret_cast<f4_t*>(red + (192 + lane) * 4);
+      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dgamma + c * 4 + k, s[k]);
+    }
+    __syncthreads();
+    *reinterpret_cast<f4_t*>(red + (w * 64 + lane) * 4) = ab[i];
+    __syncthreads();
+    if (w == 0 && c < nv) {
+      f4_t s = *reinterpret_cast<f4_t*>(red + lane * 4) + *reinterpret_cast<f4_t*>(red + (64 + lane) * 4) +
+               *reinterpret_cast<f4_t*>(red + (128 + lane) * 4) + *reinterpret_cast<f4_t*>(red + (192 + lane) * 4);
+      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dbeta + c * 4 + k, s[k]);
+    }
+  }
+}
+
+template <typename TO>
+static int ln_fwd_launch(long long M, int D, const float* x, const float* g, const float* b, float eps, void* y, float* y32, float* mean, float* rstd, hipStream_t st) {
+  dim3 grid(cdiv(M, 4)), block(256);
+  int nv = cdiv(D, 256);
+#define LNF(NVV) hipLaunchKernelGGL((ln_fwd_kernel<TO, NVV>), grid, block, 0, st, M, D, x, g, b, eps, (TO*)y, y32, mean, rstd)
+  switch (nv) { case 1: LNF(1); break; case 2: LNF(2); break; case 3: LNF(3); break; case 4: LNF(4); break; case 5: LNF(5); break; default: LNF(8); }
+#undef LNF
+  return CSMAE_OK;
+}
+
+extern "C" int csmae_layernorm_fwd(int out_dtype, long long M, int D, const float* x, const float* gamma, const float* beta, float eps,
+                                   void* y, float* y32, float* mean, float* rstd, void* stream) {
+  CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_fwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  if (out_dtype == CSMAE_BF16) ln_fwd_launch<bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, (hipStream_t)stream);
+  else if (out_dtype == CSMAE_F32) ln_fwd_launch<float>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, (hipStream_t)stream);
+  else { csmae_set_error("csmae_layernorm_fwd: bad dtype %d", out_dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_layernorm_fwd");
+}
+
+template <typename TDY, typename TLP>
+static void ln_bwd_launch(long long M, int D, const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          const float* dres_in, float* dx_out, void* dx_lp, float* dgamma, float* dbeta, hipStream_t st) {
+  int blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
+  dim3 grid(blocks), block(256);
+  int nv = cdiv(D, 256);
+#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, x, mean, rstd, gamma, dres_in, dx_out, (TLP*)dx_lp, dgamma, dbeta)
+  switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break; case 5: LNB(5); break; default: LNB(8); }
+#undef LNB
+}
+
+extern "C" int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int D, const void* dy, const float* x, const float* mean,
+                                   const float* rstd, const float* gamma, const float* dres_in, float* dx_out, void* dx_lp,
+                                   float* dgamma, float* dbeta, void* stream) {
+  CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  hipStream_t st = (hipStream_t)stream;
+  if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_BF16) ln_bwd_launch<bf16_t, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
+  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_BF16) ln_bwd_launch<float, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
+  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_F32) ln_bwd_launch<float, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
+  else if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_F32) ln_bwd_launch<bf16_t, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
+  else { csmae_set_error("csmae_layernorm_bwd: bad dtypes %d/%d", dy_dtype, lp_dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_layernorm_bwd");
+}
+
+// ------------------------------------------------------------------------------------------ BatchNorm(token axis)+ReLU
+// u is [N*L, Hp]; channel = token position l; statistics over the N*Hp values {u[n*L + l, :]} (models_mae/MLP.py:7).
+template <typename T>
+__global__ __launch_bounds__(256) void bnrelu_fwd_kernel(int N, int L, int Hp, const T* __restrict__ u, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float momentum, T* __restrict__ r,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                         float* __restrict__ run_var, long long* __restrict__ nbt) {
+  __shared__ float red[32];
+  const int l = blockIdx.x, hv = Hp >> 2;
+  const long long cnt = (long long)N * Hp;
+  float s = 0.f;
+  for (long long e = threadIdx.x; e < (long long)N * hv; e += blockDim.x) {
+    long long n = e / hv; int c = (int)(e - n * hv);
+    f4_t v = ld4<T>(u + (n * L + l) * Hp + c * 4);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  const float mu = block_sum(s, red) / cnt;
+  float q = 0.f;
+  for (long long e = threadIdx.x; e < (long long)N * hv; e += blockDim.x) {
+    long long n = e / hv; int c = (int)(e - n * hv);
+    f4_t v = ld4<T>(u + (n * L + l) * Hp + c * 4) - mu;
+    q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  const float var = block_sum(q, red) / cnt;
+  const float rs = rsqrtf(var + eps), gm = gamma[l], bt = beta[l];
+  for (long long e = threadIdx.x; e < (long long)N * hv; e += blockDim.x) {
+    long long n = e / hv; int c = (int)(e - n * hv);
+    f4_t v = (ld4<T>(u + (n * L + l) * Hp + c * 4) - mu) * rs * gm + bt;
+    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    st4<T>(r + (n * L + l) * Hp + c * 4, v);
+  }
+  if (threadIdx.x == 0) {
+    mean[l] = mu; rstd[l] = rs;
+    if (run_mean) {
+      run_mean[l] = (1.f - momentum) * run_mean[l] + momentum * mu;
+      run_var[l] = (1.f - momentum) * run_var[l] + momentum * var * ((float)cnt / (float)(cnt - 1));
+    }
+    if (nbt && l == 0) *nbt += 1;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bnrelu_bwd_kernel(int N, int L, int Hp, const T* __restrict__ u, const T* __restrict__ dr,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ du,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[32];
+  const int l = blockIdx.x, hv = Hp >> 2;
+  const long long cnt = (long long)N * Hp;
+  const float mu = mean[l], rs = rstd[l], gm = gamma[l], bt = beta[l];
+  float s1 = 0.f, s2 = 0.f;
+  for (long long e = threadIdx.x; e < (long long)N * hv; e += blockDim.x) {
+    long long n = e / hv; int c = (int)(e - n * hv);
+    long long off = (n * L + l) * Hp + c * 4;
+    f4_t xh = (ld4<T>(u + off) - mu) * rs, g = ld4<T>(dr + off);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float gg = (xh[k] * gm + bt) > 0.f ? g[k] : 0.f; s1 += gg; s2 += gg * xh[k]; }
+  }
+  s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+  const float m1 = s1 / cnt, m2 = s2 / cnt;
+  for (long long e = threadIdx.x; e < (long long)N * hv; e += blockDim.x) {
+    long long n = e / hv; int c = (int)(e - n * hv);
+    long long off = (n * L + l) * Hp + c * 4;
+    f4_t xh = (ld4<T>(u + off) - mu) * rs, g = ld4<T>(dr + off), o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float gg = (xh[k] * gm + bt) > 0.f ? g[k] : 0.f; o[k] = gm * rs * (gg - m1 - xh[k] * m2); }
+    st4<T>(du + off, o);
+  }
+  if (threadIdx.x == 0) { dgamma[l] += s2; dbeta[l] += s1; }
+}
+
+extern "C" int csmae_bnrelu_fwd(int dtype, int N, int L, int Hp, const void* u, const float* gamma, const float* beta, float eps,
+                                float momentum, void* r, float* mean, float* rstd, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, void* stream) {
+  CSMAE_REQUIRE(N > 0 && L > 0 && Hp > 0 && Hp % 4 == 0, "csmae_bnrelu_fwd: bad geometry N=%d L=%d Hp=%d", N, L, Hp);
+  CSMAE_REQUIRE((long long)N * Hp > 1, "csmae_bnrelu_fwd: need more than one value per channel (torch raises the same)");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t>), dim3(L), dim3(256), 0, st, N, L, Hp, (const bf16_t*)u, gamma, beta, eps, momentum, (bf16_t*)r, mean, rstd, running_mean, running_var, num_batches_tracked);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_fwd_kernel<float>), dim3(L), dim3(256), 0, st, N, L, Hp, (const float*)u, gamma, beta, eps, momentum, (float*)r, mean, rstd, running_mean, running_var, num_batches_tracked);
+  else { csmae_set_error("csmae_bnrelu_fwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_bnrelu_fwd");
+}
+
+extern "C" int csmae_bnrelu_bwd(int dtype, int N, int L, int Hp, const void* u, const void* dr, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, void* du, float* dgamma, float* dbeta, void* stream) {
+  CSMAE_REQUIRE(N > 0 && L > 0 && Hp > 0 && Hp % 4 == 0, "csmae_bnrelu_bwd: bad geometry N=%d L=%d Hp=%d", N, L, Hp);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_bwd_kernel<bf16_t>), dim3(L), dim3(256), 0, st, N, L, Hp, (const bf16_t*)u, (const bf16_t*)dr, gamma, beta, mean, rstd, (bf16_t*)du, dgamma, dbeta);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_bwd_kernel<float>), dim3(L), dim3(256), 0, st, N, L, Hp, (const float*)u, (const float*)dr, gamma, beta, mean, rstd, (float*)du, dgamma, dbeta);
+  else { csmae_set_error("csmae_bnrelu_bwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_bnrelu_bwd");
+}

@@ -1,0 +1,244 @@
+// Token plumbing around the transformer stacks (all HBM/latency bound, integer + copy work):
+//   crop_resize      MAE_ViT_MsLd.py:29-35,52  (one RandomResizedCrop box per batch, bilinear anti-aliased resize)
+//   mask_sort        MAE_ViT_Shared.py:57-84   (random_masking: argsort x2, mask)       -- bit-exact contract
+//   patch_gather     timm PatchEmbed on KEPT patches only (MAE_ViT_Baseline.py:245,251)
+//   embed_assemble   + encoder_pos_embed, cls prepend (MAE_ViT_Baseline.py:248,253-256)
+//   unshuffle        forward_decoder's mask-token fill + gather(ids_restore) + decoder_pos_embed (:273-283)
+//   rows_gather/scatter  "[:, 1:, :]" views feeding the predictor (MAE_ViT_MsLdCeCd.py:57-58)
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ crop + AA bilinear resize
+// Follows ATen's separable anti-aliased bilinear filter (triangle filter, support = max(scale, 1), weights
+// renormalised), horizontal pass first, in float.  `box` = device int[4] {top i, left j, height h, width w}.
+struct AxisTaps { int lo, n; float w[8]; };
+__device__ __forceinline__ void aa_taps(int o, int in_size, int out_size, AxisTaps& tp) {
+  const float scale = (float)in_size / (float)out_size;
+  const float support = scale >= 1.f ? scale : 1.f;
+  const float inv = scale >= 1.f ? 1.f / scale : 1.f;
+  const float center = scale * (o + 0.5f);
+  int lo = (int)(center - support + 0.5f); lo = lo < 0 ? 0 : lo;
+  int hi = (int)(center + support + 0.5f); hi = hi > in_size ? in_size : hi;
+  int n = hi - lo; n = n > 8 ? 8 : n;
+  float tot = 0.f;
+  for (int k = 0; k < n; ++k) { float a = fabsf((k + lo - center + 0.5f) * inv); float w = a < 1.f ? 1.f - a : 0.f; tp.w[k] = w; tot += w; }
+  for (int k = 0; k < n; ++k) tp.w[k] /= tot;
+  tp.lo = lo; tp.n = n;
+}
+__global__ __launch_bounds__(256) void crop_resize_kernel(long long planes, int S, const float* __restrict__ src, float* __restrict__ dst,
+                                                          const int* __restrict__ box) {
+  const int bi = box[0], bj = box[1], bh = box[2], bw = box[3];
+  const int oy = blockIdx.y;
+  AxisTaps ty; aa_taps(oy, bh, S, ty);
+  for (int ox = threadIdx.x; ox < S; ox += blockDim.x) {
+    AxisTaps tx; aa_taps(ox, bw, S, tx);
+    for (long long pl = blockIdx.x; pl < planes; pl += gridDim.x) {
+      const float* base = src + pl * S * S + (long long)(bi + ty.lo) * S + bj + tx.lo;
+      float acc = 0.f;
+      for (int a = 0; a < ty.n; ++a) {
+        float hsum = 0.f;
+        for (int b = 0; b < tx.n; ++b) hsum += tx.w[b] * base[a * S + b];
+        acc += ty.w[a] * hsum;
+      }
+      dst[pl * S * S + (long long)oy * S + ox] = acc;
+    }
+  }
+}
+extern "C" int csmae_crop_resize(long long planes, int S, const float* src, float* dst, const int* box, void* stream) {
+  CSMAE_REQUIRE(planes > 0 && S > 0 && src && dst && box, "csmae_crop_resize: bad args");
+  dim3 grid((unsigned)fmin((double)planes, 1024.0), S), block(S >= 256 ? 256 : ((S + 63) / 64) * 64);
+  hipLaunchKernelGGL(crop_resize_kernel, grid, block, 0, (hipStream_t)stream, planes, S, src, dst, box);
+  return csmae_check_launch("csmae_crop_resize");
+}
+
+// ------------------------------------------------------------------------------------------ random_masking indices
+// rank sort (stable ascending): rank(i) = #{j : noise[j] < noise[i] or (noise[j] == noise[i] and j < i)}.
+// ids_shuffle[rank] = i ; ids_restore[i] = rank ; mask[i] = rank >= keep.  (ids_restore = argsort(ids_shuffle) exactly,
+// because ids_shuffle is a permutation.)
+__global__ __launch_bounds__(256) void mask_sort_kernel(int L, int keep, const float* __restrict__ noise, long long* __restrict__ ids_restore,
+                                                        float* __restrict__ mask, int* __restrict__ ids_keep, int* __restrict__ ids_shuffle) {
+  extern __shared__ float nz[];
+  const long long row = blockIdx.x;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) nz[i] = noise[row * L + i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    const float v = nz[i];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) { float u = nz[j]; rank += (u < v) || (u == v && j < i); }
+    ids_restore[row * L + i] = rank;
+    mask[row * L + i] = rank >= keep ? 1.f : 0.f;
+    if (rank < keep) ids_keep[row * keep + rank] = i;
+    if (ids_shuffle) ids_shuffle[row * L + rank] = i;
+  }
+}
+extern "C" int csmae_mask_sort(long long rows, int L, int keep, const float* noise, long long* ids_restore, float* mask, int* ids_keep,
+                               int* ids_shuffle, void* stream) {
+  CSMAE_REQUIRE(rows > 0 && L > 0 && keep >= 0 && keep <= L && L <= 16384, "csmae_mask_sort: bad geometry rows=%lld L=%d keep=%d", rows, L, keep);
+  hipLaunchKernelGGL(mask_sort_kernel, dim3((unsigned)rows), dim3(256), L * sizeof(float), (hipStream_t)stream, L, keep, noise, ids_restore, mask, ids_keep, ids_shuffle);
+  return csmae_check_launch("csmae_mask_sort");
+}
+
+// ------------------------------------------------------------------------------------------ kept-patch im2col
+// out[row = n2*keep + t][c*p*p + ph*p + pw] = img_view(n2)[n][c][gh*p + ph][gw*p + pw], token l = ids_keep[row] = gh*G + gw.
+// Column order matches Conv2d weight [D, C, p, p] flattened (MAE_ViT_Baseline.py:222-224).  Pad columns [P, ld) are zeroed.
+template <typename T>
+__global__ __launch_bounds__(256) void patch_gather_kernel(int keep, int N, int C, int S, int p, const float* __restrict__ img0,
+                                                           const float* __restrict__ img1, const int* __restrict__ ids_keep,
+                                                           T* __restrict__ out, long long ld) {
+  const long long row = blockIdx.x;
+  const long long n2 = row / keep;
+  const int view = (int)(n2 / N), n = (int)(n2 - (long long)view * N);
+  const float* img = (view ? img1 : img0) + (long long)n * C * S * S;
+  const int G = S / p, l = ids_keep[row], gh = l / G, gw = l - gh * G;
+  const int P = C * p * p;
+  for (int e = threadIdx.x; e < ld; e += blockDim.x) {
+    float v = 0.f;
+    if (e < P) { int c = e / (p * p), r = e - c * p * p, ph = r / p, pw = r - ph * p; v = img[((long long)c * S + gh * p + ph) * S + gw * p + pw]; }
+    st_from_f32<T>(out + row * ld + e, v);
+  }
+}
+extern "C" int csmae_patch_gather(int dtype, long long rows, int keep, int N, int C, int S, int p, const float* img0, const float* img1,
+                                  const int* ids_keep, void* out, long long ld, void* stream) {
+  CSMAE_REQUIRE(rows > 0 && keep > 0 && N > 0 && S % p == 0 && ld >= (long long)C * p * p, "csmae_patch_gather: bad geometry");
+  CSMAE_REQUIRE(rows <= (long long)N * keep || img1, "csmae_patch_gather: second view requested but img1 is null");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((patch_gather_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, keep, N, C, S, p, img0, img1, ids_keep, (bf16_t*)out, ld);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((patch_gather_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, keep, N, C, S, p, img0, img1, ids_keep, (float*)out, ld);
+  else { csmae_set_error("csmae_patch_gather: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_patch_gather");
+}
+
+// ------------------------------------------------------------------------------------------ pos-embed add + cls prepend
+__global__ __launch_bounds__(256) void embed_assemble_kernel(int keep, int D, const float* __restrict__ tok, const float* __restrict__ pos,
+                                                             const float* __restrict__ cls, const int* __restrict__ ids_keep, float* __restrict__ x) {
+  const long long n2 = blockIdx.x;
+  const int t = blockIdx.y;  // 0 = cls
+  const int dv = D >> 2;
+  float* dst = x + (n2 * (keep + 1) + t) * D;
+  if (t == 0) {
+    for (int c = threadIdx.x; c < dv; c += blockDim.x) *reinterpret_cast<f4_t*>(dst + c * 4) = *reinterpret_cast<const f4_t*>(cls + c * 4) + *reinterpret_cast<const f4_t*>(pos + c * 4);
+  } else {
+    const long long r = n2 * keep + t - 1;
+    const float* pp = pos + (long long)(1 + ids_keep[r]) * D;
+    for (int c = threadIdx.x; c < dv; c += blockDim.x) *reinterpret_cast<f4_t*>(dst + c * 4) = *reinterpret_cast<const f4_t*>(tok + r * D + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4);
+  }
+}
+extern "C" int csmae_embed_assemble(long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep, float* x, void* stream) {
+  CSMAE_REQUIRE(B2 > 0 && keep >= 0 && D % 4 == 0, "csmae_embed_assemble: bad geometry");
+  hipLaunchKernelGGL(embed_assemble_kernel, dim3((unsigned)B2, keep + 1), dim3(D >= 1024 ? 256 : 128), 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, x);
+  return csmae_check_launch("csmae_embed_assemble");
+}
+// backward: dtok[n2*keep + t] = dx[n2, 1+t] (cast) ; dcls += sum_n2 dx[n2, 0]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(long long B2, int keep, int D, const float* __restrict__ dx, T* __restrict__ dtok, float* __restrict__ dcls) {
+  const int dv = D >> 2;
+  if (blockIdx.y == 0) {  // cls column sums: blocks along x split the columns
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dv; c += gridDim.x * blockDim.x) {
+      f4_t s = {0.f, 0.f, 0.f, 0.f};
+      for (long long n = 0; n < B2; ++n) s += *reinterpret_cast<const f4_t*>(dx + n * (keep + 1) * D + c * 4);
+      f4_t o = *reinterpret_cast<f4_t*>(dcls + c * 4) + s;
+      *reinterpret_cast<f4_t*>(dcls + c * 4) = o;
+    }
+    return;
+  }
+  const int t = blockIdx.y - 1;
+  for (long long n2 = blockIdx.x; n2 < B2; n2 += gridDim.x)
+    for (int c = threadIdx.x; c < dv; c += blockDim.x)
+      st4<T>(dtok + (n2 * keep + t) * D + c * 4, *reinterpret_cast<const f4_t*>(dx + (n2 * (keep + 1) + 1 + t) * D + c * 4));
+}
+extern "C" int csmae_embed_assemble_bwd(int dtype, long long B2, int keep, int D, const float* dx, void* dtok, float* dcls, void* stream) {
+  CSMAE_REQUIRE(B2 > 0 && keep >= 0 && D % 4 == 0, "csmae_embed_assemble_bwd: bad geometry");
+  dim3 grid((unsigned)fmin((double)B2, 512.0), keep + 1), block(128);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((embed_assemble_bwd_kernel<bf16_t>), grid, block, 0, st, B2, keep, D, dx, (bf16_t*)dtok, dcls);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((embed_assemble_bwd_kernel<float>), grid, block, 0, st, B2, keep, D, dx, (float*)dtok, dcls);
+  else { csmae_set_error("csmae_embed_assemble_bwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_embed_assemble_bwd");
+}
+
+// ------------------------------------------------------------------------------------------ decoder unshuffle
+// xd[n,0] = z[n,0] + dpos[0];  xd[n,1+j] = (r = ids_restore[n,j]) < keep ? z[n,1+r] : mask_token ;  + dpos[1+j]
+__global__ __launch_bounds__(128) void unshuffle_fwd_kernel(int L, int keep, int Dd, const float* __restrict__ z, const float* __restrict__ mask_token,
+                                                            const float* __restrict__ dpos, const long long* __restrict__ ids_restore, float* __restrict__ xd) {
+  const long long n = blockIdx.x;
+  const int j = blockIdx.y;  // 0 = cls
+  const int dv = Dd >> 2;
+  const float* src;
+  if (j == 0) src = z + n * (keep + 1) * Dd;
+  else { long long r = ids_restore[n * L + j - 1]; src = r < keep ? z + (n * (keep + 1) + 1 + r) * Dd : mask_token; }
+  float* dst = xd + (n * (L + 1) + j) * Dd;
+  const float* pp = dpos + (long long)j * Dd;
+  for (int c = threadIdx.x; c < dv; c += blockDim.x)
+    *reinterpret_cast<f4_t*>(dst + c * 4) = *reinterpret_cast<const f4_t*>(src + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4);
+}
+extern "C" int csmae_unshuffle_fwd(long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
+                                   const long long* ids_restore, float* xd, void* stream) {
+  CSMAE_REQUIRE(B2 > 0 && L > 0 && keep >= 0 && keep <= L && Dd % 4 == 0, "csmae_unshuffle_fwd: bad geometry");
+  hipLaunchKernelGGL(unshuffle_fwd_kernel, dim3((unsigned)B2, L + 1), dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, xd);
+  return csmae_check_launch("csmae_unshuffle_fwd");
+}
+// backward: kept tokens are routed back (unique writers: ids_restore is a permutation), masked positions sum into dmask_token
+template <typename T>
+__global__ __launch_bounds__(128) void unshuffle_bwd_kernel(int L, int keep, int Dd, const float* __restrict__ dxd, const long long* __restrict__ ids_restore,
+                                                            T* __restrict__ dz, float* __restrict__ dmask_token) {
+  const long long n = blockIdx.x;
+  const int dv = Dd >> 2;
+  for (int c = threadIdx.x; c < dv; c += blockDim.x) {
+    f4_t acc = {0.f, 0.f, 0.f, 0.f};
+    st4<T>(dz + n * (keep + 1) * Dd + c * 4, *reinterpret_cast<const f4_t*>(dxd + n * (L + 1) * Dd + c * 4));
+    for (int j = 0; j < L; ++j) {
+      long long r = ids_restore[n * L + j];
+      f4_t g = *reinterpret_cast<const f4_t*>(dxd + (n * (L + 1) + 1 + j) * Dd + c * 4);
+      if (r < keep) st4<T>(dz + (n * (keep + 1) + 1 + r) * Dd + c * 4, g); else acc += g;
+    }
+    for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dmask_token + c * 4 + k, acc[k]);
+  }
+}
+extern "C" int csmae_unshuffle_bwd(int dtype, long long B2, int L, int keep, int Dd, const float* dxd, const long long* ids_restore, void* dz,
+                                   float* dmask_token, void* stream) {
+  CSMAE_REQUIRE(B2 > 0 && L > 0 && keep >= 0 && keep <= L && Dd % 4 == 0, "csmae_unshuffle_bwd: bad geometry");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((unshuffle_bwd_kernel<bf16_t>), dim3((unsigned)B2), dim3(128), 0, st, L, keep, Dd, dxd, ids_restore, (bf16_t*)dz, dmask_token);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((unshuffle_bwd_kernel<float>), dim3((unsigned)B2), dim3(128), 0, st, L, keep, Dd, dxd, ids_restore, (float*)dz, dmask_token);
+  else { csmae_set_error("csmae_unshuffle_bwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_unshuffle_bwd");
+}
+
+// ------------------------------------------------------------------------------------------ strided row views
+// view row r -> storage row (r / group) * gstride + off + r % group
+template <typename T>
+__global__ __launch_bounds__(128) void rows_gather_kernel(long long rows, int D, const float* __restrict__ src, long long group, long long gstride, long long off, T* __restrict__ dst) {
+  const int dv = D >> 2;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float* s = src + ((r / group) * gstride + off + r % group) * D;
+    for (int c = threadIdx.x; c < dv; c += blockDim.x) st4<T>(dst + r * D + c * 4, *reinterpret_cast<const f4_t*>(s + c * 4));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(128) void rows_scatter_add_kernel(long long rows, int D, const T* __restrict__ src, float scale, long long group, long long gstride, long long off, float* __restrict__ dst) {
+  const int dv = D >> 2;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    float* d = dst + ((r / group) * gstride + off + r % group) * D;
+    for (int c = threadIdx.x; c < dv; c += blockDim.x) {
+      f4_t o = *reinterpret_cast<f4_t*>(d + c * 4) + ld4<T>(src + r * D + c * 4) * scale;
+      *reinterpret_cast<f4_t*>(d + c * 4) = o;
+    }
+  }
+}
+extern "C" int csmae_rows_gather(int dtype, long long rows, int D, const float* src, long long group, long long gstride, long long off, void* dst, void* stream) {
+  CSMAE_REQUIRE(rows > 0 && D % 4 == 0 && group > 0, "csmae_rows_gather: bad geometry");
+  dim3 grid((unsigned)fmin((double)rows, 4096.0)), block(128);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((rows_gather_kernel<bf16_t>), grid, block, 0, st, rows, D, src, group, gstride, off, (bf16_t*)dst);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((rows_gather_kernel<float>), grid, block, 0, st, rows, D, src, group, gstride, off, (float*)dst);
+  else { csmae_set_error("csmae_rows_gather: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_rows_gather");
+}
+extern "C" int csmae_rows_scatter_add(int dtype, long long rows, int D, const void* src, float scale, long long group, long long gstride, long long off, float* dst, void* stream) {
+  CSMAE_REQUIRE(rows > 0 && D % 4 == 0 && group > 0, "csmae_rows_scatter_add: bad geometry");
+  dim3 grid((unsigned)fmin((double)rows, 4096.0)), block(128);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((rows_scatter_add_kernel<bf16_t>), grid, block, 0, st, rows, D, (const bf16_t*)src, scale, group, gstride, off, dst);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((rows_scatter_add_kernel<float>), grid, block, 0, st, rows, D, (const float*)src, scale, group, gstride, off, dst);
+  else { csmae_set_error("csmae_rows_scatter_add: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_rows_scatter_add");
+}

@@ -1,0 +1,127 @@
+/* libcsmae_hip — C ABI of the MI355X (gfx950) Cross-Scale MAE pre-training hot path.
+ *
+ * The reference (aicip/Cross-Scale-MAE) is pure Python and has NO native/FFI boundary of its own
+ * (SURVEY §8b): its "operators" are ATen/timm calls inside `models_mae/*.py` and `engine_pretrain.py`.
+ * Each entry point below therefore cites the reference expression it replaces (paths relative to the
+ * reference root) rather than a pre-existing FFI symbol.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous memory owned by the caller (PyTorch allocates);
+ *     kernels never allocate, free or retain pointers;
+ *   - `stream` is a hipStream_t; calls only enqueue work and return immediately (no implicit sync);
+ *   - return 0 on success, negative csmae_status otherwise; csmae_last_error() gives a thread-local text;
+ *   - dtype: CSMAE_F32 = 0 (exact-fp32 parity mode), CSMAE_BF16 = 1 (MFMA throughput mode; raw bf16 bits);
+ *   - row "views": storage_row(r) = (r / group) * gstride + off + r % group  (the `[:, 1:, :]` slices);
+ *   - scalars that change every step (crop box, upstream gradient, AdamW hyper-parameters) are read from
+ *     device memory so a captured hipGraph of the step stays valid.
+ */
+#ifndef CSMAE_H
+#define CSMAE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSMAE_F32 0
+#define CSMAE_BF16 1
+
+enum csmae_status { CSMAE_OK = 0, CSMAE_ERR_ARG = -1, CSMAE_ERR_LAUNCH = -2, CSMAE_ERR_UNSUPPORTED = -3 };
+enum csmae_epilogue { CSMAE_EPI_NONE = 0, CSMAE_EPI_GELU = 1, CSMAE_EPI_RESID = 2, CSMAE_EPI_DGELU = 3, CSMAE_EPI_ATOMIC = 4 };
+enum csmae_loss { CSMAE_LOSS_MSE = 0, CSMAE_LOSS_L2 = 1, CSMAE_LOSS_MAE = 2, CSMAE_LOSS_L1 = 3, CSMAE_LOSS_BCE = 4 };
+
+const char* csmae_last_error(void);
+int csmae_abi_version(void);
+
+/* ---- dense contractions: nn.Linear of timm Block / decoder_embed / decoder_pred / predictor and their backward
+ * (timm 0.4.12 Attention.qkv/.proj, Mlp.fc1/.fc2 — call sites models_mae/MAE_ViT_Baseline.py:160-188,270,295;
+ *  models_mae/MLP.py:6,9).  C[M,N] = sum_k A(m,k) B(k,n); transX = 0: K contiguous ([M,K] / [N,K]); 1: K strided ([K,M] / [K,N]).
+ *  epilogue: NONE (+bias) | GELU (aux = pre-activation, C = gelu) | RESID (C = acc + bias + resid, fp32) |
+ *            DGELU (C = acc * gelu'(aux)) | ATOMIC (fp32 C += acc; split-K weight gradients). */
+int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long long K,
+               const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int c_dtype,
+               const float* bias, int epilogue, void* aux, long long ldaux, const float* resid, long long ldr,
+               int splitk, void* stream);
+
+/* ---- softmax attention of timm Block (Attention.forward: softmax(q k^T * hd^-0.5) v), qkv is [B*T, 3*H*hd]
+ * in timm's (3, H, hd) column order; out [B*T, H*hd]; lse [B, H, T] (natural log). */
+int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* stream);
+int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
+                   const float* lse, void* dqkv, void* stream);
+
+/* ---- nn.LayerNorm(eps=1e-6) (MAE_ViT_Baseline.py:43-45): x fp32 [M,D]; y in out_dtype (+ optional fp32 copy y32).
+ * bwd: dx_out = dres_in + LN'(dy); dx_lp = low-precision copy for the next GEMM; dgamma/dbeta += (atomic). */
+int csmae_layernorm_fwd(int out_dtype, long long M, int D, const float* x, const float* gamma, const float* beta, float eps,
+                        void* y, float* y32, float* mean, float* rstd, void* stream);
+int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int D, const void* dy, const float* x, const float* mean,
+                        const float* rstd, const float* gamma, const float* dres_in, float* dx_out, void* dx_lp,
+                        float* dgamma, float* dbeta, void* stream);
+
+/* ---- predictor BatchNorm1d(num_patches) + ReLU (models_mae/MLP.py:7-8): channel = token position, batch statistics
+ * over (sample, feature); updates running stats (momentum, unbiased var) and num_batches_tracked in place. */
+int csmae_bnrelu_fwd(int dtype, int N, int L, int Hp, const void* u, const float* gamma, const float* beta, float eps,
+                     float momentum, void* r, float* mean, float* rstd, float* running_mean, float* running_var,
+                     long long* num_batches_tracked, void* stream);
+int csmae_bnrelu_bwd(int dtype, int N, int L, int Hp, const void* u, const void* dr, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, void* du, float* dgamma, float* dbeta, void* stream);
+
+/* ---- MAE_ViT_MsLd.py:29-35,52: crop box (device int[4] i,j,h,w) + bilinear anti-aliased resize back to SxS */
+int csmae_crop_resize(long long planes, int S, const float* src, float* dst, const int* box, void* stream);
+/* ---- MAE_ViT_Shared.random_masking (:57-84): stable ascending argsort of noise; int64 ids_restore, f32 mask, kept ids */
+int csmae_mask_sort(long long rows, int L, int keep, const float* noise, long long* ids_restore, float* mask, int* ids_keep,
+                    int* ids_shuffle, void* stream);
+/* ---- timm PatchEmbed on the kept patches (MAE_ViT_Baseline.py:245,251): im2col rows for the patch-embed GEMM */
+int csmae_patch_gather(int dtype, long long rows, int keep, int N, int C, int S, int p, const float* img0, const float* img1,
+                       const int* ids_keep, void* out, long long ld, void* stream);
+/* ---- MAE_ViT_Baseline.py:248,253-256: + encoder_pos_embed, cls prepend (and its backward) */
+int csmae_embed_assemble(long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep,
+                         float* x, void* stream);
+int csmae_embed_assemble_bwd(int dtype, long long B2, int keep, int D, const float* dx, void* dtok, float* dcls, void* stream);
+/* ---- MAE_ViT_Baseline.forward_decoder (:273-283): mask-token fill, gather(ids_restore), + decoder_pos_embed */
+int csmae_unshuffle_fwd(long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
+                        const long long* ids_restore, float* xd, void* stream);
+int csmae_unshuffle_bwd(int dtype, long long B2, int L, int keep, int Dd, const float* dxd, const long long* ids_restore, void* dz,
+                        float* dmask_token, void* stream);
+/* ---- `[:, 1:, :]` views around the predictor (MAE_ViT_MsLdCeCd.py:57-58) */
+int csmae_rows_gather(int dtype, long long rows, int D, const float* src, long long group, long long gstride, long long off,
+                      void* dst, void* stream);
+int csmae_rows_scatter_add(int dtype, long long rows, int D, const void* src, float scale, long long group, long long gstride,
+                           long long off, float* dst, void* stream);
+
+/* ---- MAE_ViT_Shared.forward_loss (:269-290) with process_target/patchify fused (:24-39,97-111).
+ * pred is [B2*(L+1), ldp] (row 0 of every sample = cls, ignored); rowloss [B2*L]. */
+int csmae_target_minmax(int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
+                        float* scratch, float* out, void* stream);
+int csmae_recon_loss_fwd(int kind, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
+                         const float* pred, long long ldp, const float* minmax, float* rowloss, void* stream);
+int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, long long B2, int N, int C, int S, int p, const float* img0,
+                         const float* img1, const float* pred, long long ldp, const float* minmax, const float* mask,
+                         const float* losses, const float* gout, float vscale, void* dpred, long long ldd, void* stream);
+/* ---- un-masked `.mean()` losses: cross-decoder (MAE_ViT_MsLdCeCd.py:56-59, target NOT detached) and latent (MsLdLe.py:44) */
+int csmae_pair_loss_fwd(int kind, long long rows, int D, const float* a, long long a_group, long long a_gstride, long long a_off,
+                        const float* t, long long t_group, long long t_gstride, long long t_off, float* partial, void* stream);
+int csmae_pair_loss_bwd(int kind, int lp_dtype, long long rows, int D, const float* a, long long a_group, long long a_gstride,
+                        long long a_off, const float* t, long long t_group, long long t_gstride, long long t_off,
+                        const float* gout, float coef, void* da_lp, float* da_acc, float* dt_acc, void* stream);
+/* ---- util/contrast_loss.NTXentLoss(bs, 0.5, cos_sim=True) on mean-pooled latents (MAE_ViT_MsLdCeCd.py:61-69) */
+int csmae_ntxent_fwd(int N, int Te, int keep, int D, const float* latent, float tau, float eps, float* z, float* inv_norm,
+                     float* E, float* neg, float* rowloss, void* stream);
+int csmae_ntxent_bwd(int N, int D, const float* z, const float* inv_norm, const float* E, const float* neg, float tau, float eps,
+                     const float* gout, float* dpool, void* stream);
+int csmae_latent_grad_finish(int lp_dtype, long long B2, int Te, int D, float* dlat, const float* dpool, float inv_keep,
+                             void* dlat_lp, void* stream);
+/* ---- scalar assembly: losses[0]=total [1]=recon orig [2]=recon crop [3]=cross-decoder [4]=contrastive [5]=latent
+ *      [6],[7]=sum(mask) per view (MAE_ViT_MsLd.py:64-66, MAE_ViT_MsLdCeCd.py:72) */
+int csmae_loss_finalize(long long per_view, int views, const float* rowloss, const float* mask, float recon_scale,
+                        const float* cd_partial, float cd_scale, const float* e_partial, float e_scale,
+                        const float* ce_rowloss, int ce_rows, float* losses, void* stream);
+
+/* ---- optimizer side (main_pretrain.py:426-427 torch.optim.AdamW; util/misc.py:314 backward products) */
+int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
+                float* m, float* v, const float* hyper, void* p_lp, void* stream);
+int csmae_cast_f32_to_bf16(long long n, const float* src, void* dst, void* stream);
+int csmae_colsum(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

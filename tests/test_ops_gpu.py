@@ -1,0 +1,440 @@
+"""Kernel-level parity: every HIP entry point (called through the C ABI) against the CPU oracle / plain torch
+fp32 on the same seeded inputs, plus the committed golden vectors where the op has one.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from csmae_hip import ops as o
+    import csmae_hip
+    csmae_hip.load()
+    return o
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def assert_close(actual, expected, rtol, atol, what=""):
+    a, e = actual.detach().float().cpu(), expected.detach().float().cpu()
+    assert a.shape == e.shape, (what, a.shape, e.shape)
+    err = (a - e).abs()
+    tol = atol + rtol * e.abs()
+    if not bool((err <= tol).all()):
+        idx = int((err - tol).argmax())
+        raise AssertionError(f"{what}: max|err|={err.max():.3e} at flat {idx}: got {a.reshape(-1)[idx]:.6g} want {e.reshape(-1)[idx]:.6g}; "
+                             f"bad={int((err > tol).sum())}/{err.numel()} ref_absmax={e.abs().max():.3e}")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+SHAPES = [(128, 128, 64), (256, 384, 192), (104, 72, 40), (8, 16, 8), (1024, 768, 768), (640, 2304, 768), (200, 512, 2048)]
+
+
+@pytest.mark.parametrize("mnk", SHAPES)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_layouts(ops, mnk, layout, dtype):
+    M, N, K = mnk
+    A = rnd(M, K, seed=1).to(dtype)
+    B = rnd(N, K, seed=2).to(dtype)  # logical B(k,n) = B[n,k]
+    bias = rnd(N, seed=3)
+    ref = A.float() @ B.float().t() + bias
+    ta, tb = layout[0] == "t", layout[1] == "n"
+    a_st = A.t().contiguous() if ta else A
+    b_st = B.t().contiguous() if tb else B
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm(dev(a_st), dev(b_st), out, trans_a=ta, trans_b=tb, bias=dev(bias))
+    tol = 2e-5 if dtype == torch.float32 else 1e-4
+    assert_close(out, ref, tol, tol * K ** 0.5, f"gemm {layout} {mnk} {dtype}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 200, 256, 136
+    A, B, bias = rnd(M, K, seed=4).to(dtype), rnd(N, K, seed=5, scale=0.1).to(dtype), rnd(N, seed=6)
+    pre = A.float() @ B.float().t() + bias
+    # GELU: writes pre-activation + activation in the operand dtype
+    out, aux = torch.empty(M, N, device="cuda", dtype=dtype), torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(dev(A), dev(B), out, bias=dev(bias), epilogue=1, aux=aux)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert_close(aux, pre, tol, tol, "gelu aux")
+    assert_close(out, torch.nn.functional.gelu(aux.float().cpu()), tol, tol, "gelu out")
+    # residual: fp32 in/out
+    R = rnd(M, N, seed=7)
+    o32 = torch.empty(M, N, device="cuda")
+    ops.gemm(dev(A), dev(B), o32, bias=dev(bias), epilogue=2, resid=dev(R))
+    assert_close(o32, pre + R, 1e-5 if dtype == torch.float32 else 1e-4, 1e-4, "resid")
+    # in-place residual (resid aliases out) is what the block uses
+    x = dev(R.clone())
+    ops.gemm(dev(A), dev(B), x, bias=dev(bias), epilogue=2, resid=x)
+    assert_close(x, pre + R, 1e-5 if dtype == torch.float32 else 1e-4, 1e-4, "resid in place")
+    # dGELU: out = acc * gelu'(aux)
+    P = rnd(M, N, seed=8).to(dtype)
+    pf = P.float().requires_grad_(True)
+    torch.nn.functional.gelu(pf).sum().backward()
+    od = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(dev(A), dev(B), od, epilogue=3, aux=dev(P))
+    assert_close(od, (A.float() @ B.float().t()) * pf.grad, tol, tol, "dgelu")
+    # atomic split-K accumulate on top of existing content (weight-gradient form: both operands K-strided)
+    Kt = 1000
+    dY, X = rnd(Kt, 64, seed=9).to(dtype), rnd(Kt, 48, seed=10).to(dtype)
+    acc0 = rnd(64, 48, seed=11)
+    acc = dev(acc0.clone())
+    ops.gemm(dev(dY), dev(X), acc, trans_a=True, trans_b=True, epilogue=4, splitk=5)
+    assert_close(acc, acc0 + dY.float().t() @ X.float(), 1e-4, 1e-3, "atomic splitk")
+
+
+def test_gemm_rejects_bad_args(ops):
+    import csmae_hip
+    a = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)  # K = 12 not a multiple of 8
+    with pytest.raises(csmae_hip.CsmaeError):
+        ops.gemm(a, a, torch.zeros(8, 8, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+ATT = [(3, 50, 2, 64), (2, 197, 2, 32), (2, 17, 3, 32), (2, 5, 2, 64), (1, 65, 2, 80), (1, 257, 1, 32), (2, 33, 2, 16), (1, 224, 1, 64)]
+
+
+@pytest.mark.parametrize("geom", ATT)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention_fwd_bwd(ops, geom, dtype):
+    B, T, H, hd = geom
+    D = H * hd
+    if dtype == torch.float32 and 4 * T * (hd + 1) * 4 > 160 * 1024:
+        pytest.skip("fp32 parity-mode attention keeps Q,K,V,dO of one head in LDS: T*(hd+1)*16 B must fit 160 KiB")
+    qkv = rnd(B * T, 3 * D, seed=20).to(dtype)
+    dout = rnd(B * T, D, seed=21).to(dtype)
+    q32 = qkv.float().requires_grad_(True)
+    q, k, v = q32.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * T, D)
+    ref.backward(dout.float())
+    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1)
+    out = torch.full((B * T, D), float("nan"), device="cuda", dtype=dtype)
+    lse = torch.empty(B, H, T, device="cuda")
+    dqkv = torch.full((B * T, 3 * D), float("nan"), device="cuda", dtype=dtype)
+    gq = dev(qkv)
+    ops.attn_fwd(gq, out, lse, B, T, H, hd)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert_close(out, ref, tol, tol, f"attn out {geom}")
+    assert_close(lse, lse_ref, 1e-4 if dtype == torch.float32 else 2e-2, 1e-4 if dtype == torch.float32 else 2e-2, "lse")
+    ops.attn_bwd(gq, out, dev(dout), lse, dqkv, B, T, H, hd)
+    gscale = q32.grad.abs().max().item()
+    assert_close(dqkv, q32.grad, tol, tol * max(gscale, 1.0), f"attn dqkv {geom}")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("MD", [(37, 768), (200, 512), (9, 64), (5, 128), (16, 1024), (7, 1280)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_layernorm(ops, MD, dtype):
+    M, D = MD
+    x = rnd(M, D, seed=30, scale=2.0) + 0.5
+    g, b = rnd(D, seed=31) * 0.2 + 1.0, rnd(D, seed=32) * 0.1
+    dy = rnd(M, D, seed=33).to(dtype)
+    dres = rnd(M, D, seed=34)
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    ref.backward(dy.float())
+    y = torch.empty(M, D, device="cuda", dtype=dtype)
+    y32 = torch.empty(M, D, device="cuda")
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), y, mean, rstd, y32=y32)
+    assert_close(y32, ref, 1e-5, 1e-5, "ln y32")
+    assert_close(y, ref, 1e-5 if dtype == torch.float32 else 1e-2, 1e-5 if dtype == torch.float32 else 1e-2, "ln y")
+    dx, dxlp = torch.empty(M, D, device="cuda"), torch.empty(M, D, device="cuda", dtype=dtype)
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dx, dg, db, dres_in=dev(dres), dx_lp=dxlp)
+    assert_close(dx, xr.grad + dres, 1e-4, 1e-4, "ln dx")
+    assert_close(dxlp, xr.grad + dres, 1e-4 if dtype == torch.float32 else 1e-2, 1e-4 if dtype == torch.float32 else 2e-2, "ln dx lp")
+    assert_close(dg, gr.grad, 1e-4, 1e-3, "ln dgamma")
+    assert_close(db, br.grad, 1e-4, 1e-3, "ln dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_bnrelu_token_axis(ops, dtype):
+    N, L, Hp = 6, 9, 64
+    u = (rnd(N * L, Hp, seed=40) * 1.5 + 0.3).to(dtype)
+    gamma, beta = rnd(L, seed=41) * 0.3 + 1.0, rnd(L, seed=42) * 0.2
+    dr = rnd(N * L, Hp, seed=43).to(dtype)
+    bn = torch.nn.BatchNorm1d(L)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    bn.train()
+    ur = u.float().reshape(N, L, Hp).requires_grad_(True)
+    ref = torch.relu(bn(ur))
+    ref.backward(dr.float().reshape(N, L, Hp))
+    r = torch.empty(N * L, Hp, device="cuda", dtype=dtype)
+    mean, rstd = torch.empty(L, device="cuda"), torch.empty(L, device="cuda")
+    rm, rv, nbt = torch.zeros(L, device="cuda"), torch.ones(L, device="cuda"), torch.zeros((), device="cuda", dtype=torch.long)
+    ops.bnrelu_fwd(dev(u), dev(gamma), dev(beta), r, mean, rstd, N, L, rm, rv, nbt)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert_close(r, ref.reshape(N * L, Hp), tol, tol, "bn relu")
+    assert_close(rm, bn.running_mean, 1e-5, 1e-6, "running_mean")
+    assert_close(rv, bn.running_var, 1e-5, 1e-6, "running_var")
+    assert int(nbt) == 1
+    du = torch.empty(N * L, Hp, device="cuda", dtype=dtype)
+    dg, db = torch.zeros(L, device="cuda"), torch.zeros(L, device="cuda")
+    ops.bnrelu_bwd(dev(u), dev(dr), dev(gamma), dev(beta), mean, rstd, du, dg, db, N, L)
+    assert_close(du, ur.grad.reshape(N * L, Hp), tol, tol, "bn du")
+    assert_close(dg, bn.weight.grad, 1e-4, 1e-3, "bn dgamma")
+    assert_close(db, bn.bias.grad, 1e-4, 1e-3, "bn dbeta")
+
+
+# ------------------------------------------------------------------------------------------------ token plumbing
+@pytest.mark.parametrize("L", [16, 196, 256])
+@pytest.mark.parametrize("mr", [0.75, 0.5])
+def test_mask_sort_bit_exact_vs_reference(ops, L, mr):
+    d = np.load(os.path.join(G, "masking.npz"))
+    noise = torch.from_numpy(d[f"noise_L{L}"])
+    ties = d[f"tie_rows_L{L}"].astype(bool)
+    N = noise.shape[0]
+    keep = int(L * (1 - mr))
+    ids_restore = torch.empty(N, L, device="cuda", dtype=torch.long)
+    mask = torch.empty(N, L, device="cuda")
+    ids_keep = torch.empty(N, keep, device="cuda", dtype=torch.int32)
+    ids_shuffle = torch.empty(N, L, device="cuda", dtype=torch.int32)
+    ops.mask_sort(dev(noise), keep, ids_restore, mask, ids_keep, ids_shuffle)
+    tag = f"L{L}_mr{int(mr * 100)}"
+    free = ~ties
+    assert np.array_equal(ids_restore.cpu().numpy()[free], d[f"ids_restore_{tag}"][free])  # bit-exact vs the reference
+    assert np.array_equal(mask.cpu().numpy()[free], d[f"mask_{tag}"][free])
+    stable = torch.argsort(noise, dim=1, stable=True)
+    assert torch.equal(ids_shuffle.cpu().long(), stable)  # tie rows: the stable order
+    assert torch.equal(ids_keep.cpu().long(), stable[:, :keep])
+    assert torch.equal(ids_restore.cpu(), torch.argsort(stable, dim=1))
+
+
+def test_crop_resize_vs_reference_golden(ops):
+    d = np.load(os.path.join(G, "crop.npz"))
+    imgs = torch.from_numpy(d["imgs64"])
+    for n, box in enumerate(d["boxes64"]):
+        out = torch.empty_like(imgs, device="cuda")
+        ops.crop_resize(dev(imgs), out, torch.tensor(box, dtype=torch.int32, device="cuda"))
+        assert_close(out, torch.from_numpy(d[f"out64_{n}"]), 0, 5e-6, f"crop64 {box}")
+    big = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(int(d["seed224"][0])))
+    for n, box in enumerate(d["boxes224"]):
+        out = torch.empty_like(big, device="cuda")
+        ops.crop_resize(dev(big), out, torch.tensor(box, dtype=torch.int32, device="cuda"))
+        assert_close(out.reshape(-1)[torch.from_numpy(d["idx224"]).cuda()], torch.from_numpy(d[f"val224_{n}"]), 0, 5e-6, f"crop224 {box}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("geom", [(3, 3, 64, 16), (2, 4, 128, 16), (2, 3, 56, 14)])
+def test_patch_embed_kept_tokens(ops, dtype, geom):
+    N, C, S, p = geom
+    G_, D = S // p, 64
+    L = G_ * G_
+    keep = L // 4
+    img0, img1 = rnd(N, C, S, S, seed=50), rnd(N, C, S, S, seed=51)
+    W, b = rnd(D, C, p, p, seed=52, scale=0.05), rnd(D, seed=53)
+    pos, cls = rnd(L + 1, D, seed=54), rnd(D, seed=55)
+    noise = torch.rand(2 * N, L, generator=torch.Generator().manual_seed(56))
+    ids = torch.argsort(noise, dim=1, stable=True)[:, :keep]
+    full = torch.nn.functional.conv2d(torch.cat([img0, img1]).to(dtype).float(), W.to(dtype).float(), b, stride=p).flatten(2).transpose(1, 2) + pos[1:]
+    ref = torch.cat([(cls + pos[0]).expand(2 * N, 1, D), torch.gather(full, 1, ids.unsqueeze(-1).expand(-1, -1, D))], dim=1)
+    P = C * p * p
+    ld = (P + 7) // 8 * 8
+    A = torch.empty(2 * N * keep, ld, device="cuda", dtype=dtype)
+    ops.patch_gather(dev(img0), dev(img1), dev(ids.int().contiguous()), A, N, C, S, p, keep)
+    Wm = torch.zeros(D, ld, dtype=dtype)
+    Wm[:, :P] = W.reshape(D, P).to(dtype)
+    tok = torch.empty(2 * N * keep, D, device="cuda")
+    ops.gemm(A, dev(Wm), tok, bias=dev(b))
+    x = torch.empty(2 * N, keep + 1, D, device="cuda")
+    ops.embed_assemble(tok, dev(pos), dev(cls), dev(ids.int().contiguous()), x, 2 * N, keep)
+    assert_close(x, ref, 1e-4, 1e-4, "patch embed")
+    # backward plumbing
+    dx = rnd(2 * N, keep + 1, D, seed=57)
+    dtok = torch.empty(2 * N * keep, D, device="cuda", dtype=dtype)
+    dcls = torch.zeros(D, device="cuda")
+    ops.embed_assemble_bwd(dev(dx), dtok, dcls, 2 * N, keep)
+    assert_close(dtok, dx[:, 1:].reshape(-1, D), 0 if dtype == torch.float32 else 1e-2, 0 if dtype == torch.float32 else 1e-2, "dtok")
+    assert_close(dcls, dx[:, 0].sum(0), 1e-5, 1e-5, "dcls")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unshuffle_and_row_views(ops, dtype):
+    B2, L, keep, Dd = 5, 16, 4, 64
+    z = rnd(B2 * (keep + 1), Dd, seed=60)
+    mt, dpos = rnd(Dd, seed=61), rnd(L + 1, Dd, seed=62)
+    ids_restore = torch.argsort(torch.argsort(torch.rand(B2, L, generator=torch.Generator().manual_seed(63)), dim=1), dim=1)
+    zr, mtr = z.clone().requires_grad_(True), mt.clone().requires_grad_(True)
+    z3 = zr.reshape(B2, keep + 1, Dd)
+    seq = torch.cat([z3[:, 1:], mtr.expand(B2, L - keep, Dd)], dim=1)
+    seq = torch.gather(seq, 1, ids_restore.unsqueeze(-1).expand(-1, -1, Dd))
+    ref = torch.cat([z3[:, :1], seq], dim=1) + dpos
+    dxd = rnd(B2, L + 1, Dd, seed=64)
+    ref.backward(dxd)
+    xd = torch.empty(B2, L + 1, Dd, device="cuda")
+    ops.unshuffle_fwd(dev(z), dev(mt), dev(dpos), dev(ids_restore), xd, B2, L, keep)
+    assert_close(xd, ref, 0, 1e-6, "unshuffle")
+    dz = torch.full((B2 * (keep + 1), Dd), float("nan"), device="cuda", dtype=dtype)
+    dmt = torch.zeros(Dd, device="cuda")
+    ops.unshuffle_bwd(dev(dxd), dev(ids_restore), dz, dmt, B2, L, keep)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert_close(dz, zr.grad, tol, tol, "dz")
+    assert_close(dmt, mtr.grad, 1e-5, 1e-5, "dmask_token")
+    # row views: rows (n*Td + 1 + l) of the second half
+    N, Td = 2, L + 1
+    src = rnd(2 * N * Td, Dd, seed=65)
+    dst = torch.empty(N * L, Dd, device="cuda", dtype=dtype)
+    ops.rows_gather(dev(src), dst, L, Td, N * Td + 1)
+    want = src.reshape(2 * N, Td, Dd)[N:, 1:].reshape(N * L, Dd)
+    assert_close(dst, want, tol, tol, "rows_gather")
+    acc0 = rnd(2 * N * Td, Dd, seed=66)
+    acc = dev(acc0.clone())
+    ops.rows_scatter_add(dst, acc, L, Td, N * Td + 1, scale=0.5)
+    exp = acc0.clone().reshape(2 * N, Td, Dd)
+    exp[N:, 1:] += 0.5 * dst.float().cpu().reshape(N, L, Dd)
+    assert_close(acc, exp.reshape(-1, Dd), 1e-6, 1e-6, "rows_scatter_add")
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("kind", ["mse", "l2", "mae", "l1", "bce"])
+@pytest.mark.parametrize("norm_pix", [False, True])
+def test_recon_loss_fwd_bwd(ops, kind, norm_pix):
+    import csmae_oracle as O
+    N, C, S, p = 3, 3, 32, 16
+    L, P = 4, 768
+    B2 = 2 * N
+    img0, img1 = rnd(N, C, S, S, seed=70), rnd(N, C, S, S, seed=71)
+    pred_full = rnd(B2 * (L + 1), P, seed=72)
+    mask = (torch.rand(B2, L, generator=torch.Generator().manual_seed(73)) > 0.3).float()
+    mask[0, 0] = 1.0
+    pr = pred_full.clone().requires_grad_(True)
+    pv = pr.reshape(B2, L + 1, P)[:, 1:]
+    lo = O.loss_fn(kind, O.recon_target(img0, p, C, norm_pix), pv[:N], mask[:N])
+    lc = O.loss_fn(kind, O.recon_target(img1, p, C, norm_pix), pv[N:], mask[N:])
+    g = 0.7
+    ((lo + lc) * g).backward()
+    mm = None
+    if kind == "bce":
+        mm = torch.empty(4, device="cuda")
+        ops.target_minmax(dev(img0), dev(img1), torch.empty(B2 * L * 2, device="cuda"), mm, B2, N, C, S, p, norm_pix)
+    rowloss = torch.empty(B2 * L, device="cuda")
+    gp = dev(pred_full)
+    ops.recon_loss_fwd(kind, norm_pix, dev(img0), dev(img1), gp, mm, rowloss, B2, N, C, S, p)
+    losses = torch.zeros(8, device="cuda")
+    ops.loss_finalize(N * L, 2, rowloss, dev(mask), 1.0, losses)
+    assert_close(losses[1:3], torch.stack([lo, lc]), 2e-5, 1e-6, f"recon {kind}")
+    assert_close(losses[0], lo + lc, 2e-5, 1e-6, "total")
+    assert_close(losses[6:8], torch.stack([mask[:N].sum(), mask[N:].sum()]), 0, 0, "masksum")
+    gout = torch.tensor([g], device="cuda")
+    dpred = torch.full((B2 * (L + 1), P), float("nan"), device="cuda")
+    ops.recon_loss_bwd(kind, norm_pix, dev(img0), dev(img1), gp, mm, dev(mask), losses, gout, 1.0, dpred, B2, N, C, S, p)
+    assert_close(dpred, pr.grad, 1e-4, 1e-7, f"dpred {kind}")
+
+
+@pytest.mark.parametrize("kind", ["mse", "l2", "mae", "l1"])
+def test_pair_loss(ops, kind):
+    import csmae_oracle as O
+    N, L, Td, Dd = 3, 4, 5, 32
+    v = rnd(N * L, Dd, seed=80)
+    emb = rnd(2 * N * Td, Dd, seed=81)
+    vr, er = v.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    tgt = er.reshape(2 * N, Td, Dd)[:N, 1:]
+    ref = O.loss_fn(kind, tgt, vr.reshape(N, L, Dd))
+    g = 1.3
+    (ref * g).backward()
+    partial = torch.empty(512, device="cuda")
+    aview, tview = (N * L, 0, 0), (L, Td, 1)
+    ops.pair_loss_fwd(kind, N * L, Dd, dev(v), aview, dev(emb), tview, partial)
+    scale = 1.0 / (N * L * Dd) if kind in ("mse", "mae") else 1.0 / (N * L)
+    losses = torch.zeros(8, device="cuda")
+    dummy_rl, dummy_m = torch.zeros(N * L, device="cuda"), torch.ones(N * L, device="cuda")
+    ops.loss_finalize(N * L, 1, dummy_rl, dummy_m, 1.0, losses, cd_partial=partial, cd_scale=scale)
+    assert_close(losses[3], ref, 2e-5, 1e-7, f"pair {kind}")
+    gout = torch.tensor([g], device="cuda")
+    da = torch.empty(N * L, Dd, device="cuda")
+    dt_acc = torch.zeros(2 * N * Td, Dd, device="cuda")
+    ops.pair_loss_bwd(kind, N * L, Dd, dev(v), aview, dev(emb), tview, gout, scale, da_lp=da, dt_acc=dt_acc)
+    assert_close(da, vr.grad, 1e-5, 1e-8, "pair da")
+    assert_close(dt_acc, er.grad, 1e-5, 1e-8, "pair dt")
+
+
+@pytest.mark.parametrize("bs", [2, 4, 128, 16])
+def test_ntxent_vs_reference_golden(ops, bs):
+    d = np.load(os.path.join(G, "ntxent.npz"))
+    f1, f2 = torch.from_numpy(d[f"f1_{bs}"]), torch.from_numpy(d[f"f2_{bs}"])
+    D = f1.shape[1]
+    # latent [2N, Te=3, D] whose kept-token mean equals f (tokens f-d and f+d), cls row = junk
+    delta = rnd(2 * bs, D, seed=90)
+    f = torch.cat([f1, f2])
+    latent = torch.stack([rnd(2 * bs, D, seed=91), f - delta, f + delta], dim=1).contiguous()
+    z, inv = torch.empty(2 * bs, D, device="cuda"), torch.empty(2 * bs, device="cuda")
+    E, neg, rl = torch.empty(2 * bs, 2 * bs, device="cuda"), torch.empty(2 * bs, device="cuda"), torch.empty(2 * bs, device="cuda")
+    ops.ntxent_fwd(dev(latent), z, inv, E, neg, rl, bs, 3, 2)
+    losses = torch.zeros(8, device="cuda")
+    ops.loss_finalize(4, 1, torch.zeros(4, device="cuda"), torch.ones(4, device="cuda"), 1.0, losses, ce_rowloss=rl, ce_rows=2 * bs)
+    assert_close(losses[4], torch.from_numpy(d[f"loss_{bs}"]), 1e-5, 1e-6, f"ntxent {bs}")
+    gout = torch.tensor([1.0], device="cuda")
+    dpool = torch.empty(2 * bs, D, device="cuda")
+    ops.ntxent_bwd(z, inv, E, neg, gout, dpool, bs)
+    ref = torch.cat([torch.from_numpy(d[f"g1_{bs}"]), torch.from_numpy(d[f"g2_{bs}"])])
+    assert_close(dpool, ref, 2e-3, 1e-6 + 1e-3 * ref.abs().max().item(), "ntxent grad")
+    dlat = torch.zeros(2 * bs * 3, D, device="cuda")
+    lp = torch.empty(2 * bs * 3, D, device="cuda", dtype=torch.bfloat16)
+    ops.latent_grad_finish(dlat, dpool, 0.5, lp, 2 * bs, 3)
+    want = torch.stack([torch.zeros_like(ref), ref * 0.5, ref * 0.5], dim=1).reshape(-1, D)
+    assert_close(dlat, want, 2e-3, 1e-6 + 1e-3 * ref.abs().max().item(), "latent grad finish")
+    assert_close(lp, want, 2e-2, 1e-6 + 1e-2 * ref.abs().max().item(), "latent grad lp")
+
+
+# ------------------------------------------------------------------------------------------------ optimizer side
+def test_adamw_matches_torch(ops):
+    sizes, wds = [1000, 37, 4096 * 3 + 5, 64], [0.05, 0.0, 0.05, 0.0]
+    ps = [rnd(s, seed=100 + i) for i, s in enumerate(sizes)]
+    tp = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.AdamW([dict(params=[tp[0], tp[2]], weight_decay=0.05), dict(params=[tp[1], tp[3]], weight_decay=0.0)], lr=1e-3, betas=(0.9, 0.95))
+    offs = np.cumsum([0] + [(s + 3) // 4 * 4 for s in sizes])
+    total = int(offs[-1])
+    flat_p, flat_g = torch.zeros(total), torch.zeros(total)
+    m, v = torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda")
+    for i, p in enumerate(ps):
+        flat_p[offs[i]:offs[i] + sizes[i]] = p
+    toff, tcnt, twd = [], [], []
+    for i, s in enumerate(sizes):
+        for o in range(0, s, 4096):
+            toff.append(offs[i] + o); tcnt.append(min(4096, s - o)); twd.append(wds[i])
+    toff, tcnt, twd = torch.tensor(toff, device="cuda"), torch.tensor(tcnt, dtype=torch.int32, device="cuda"), torch.tensor(twd, device="cuda")
+    gp = flat_p.cuda()
+    lp = torch.zeros(total, device="cuda", dtype=torch.bfloat16)
+    for step in range(1, 4):
+        for i, p in enumerate(tp):
+            p.grad = rnd(sizes[i], seed=200 + 10 * step + i)
+            flat_g[offs[i]:offs[i] + sizes[i]] = p.grad
+        opt.step()
+        hyper = torch.tensor([1e-3, 0.9, 0.95, 1e-8, 1 - 0.9 ** step, 1 - 0.95 ** step], device="cuda")
+        ops.adamw(toff, tcnt, twd, gp, flat_g.cuda(), m, v, hyper, p_lp=lp)
+        for i, p in enumerate(tp):
+            assert_close(gp[offs[i]:offs[i] + sizes[i]], p, 1e-6, 1e-7, f"adamw step {step} tensor {i}")
+    assert_close(lp[:1000], gp[:1000], 1e-2, 1e-3, "bf16 mirror")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_colsum_and_cast(ops, dtype):
+    x = rnd(1237, 200, seed=110).to(dtype)
+    out0 = rnd(200, seed=111)
+    out = dev(out0.clone())
+    ops.colsum(dev(x), out)
+    assert_close(out, out0 + x.float().sum(0), 1e-5, 1e-3, "colsum")
+    src = rnd(10007, seed=112)
+    dst = torch.empty(10008, device="cuda", dtype=torch.bfloat16)
+    ops.cast_bf16(dev(src), dst)
+    assert torch.equal(dst[:10007].cpu(), src.to(torch.bfloat16))
