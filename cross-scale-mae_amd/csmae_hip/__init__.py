@@ -23,7 +23,7 @@ _SIGNATURES = {
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
     "csmae_layernorm_fwd": [I, L, I, P, P, P, F, P, P, P, P, P],
     "csmae_layernorm_bwd": [I, I, L, I, P, P, P, P, P, P, P, P, P, P, P],
-    "csmae_bnrelu_fwd": [I, I, I, I, P, P, P, F, F, P, P, P, P, P, P, P],
+    "csmae_bnrelu_fwd": [I, I, I, I, P, P, P, F, F, P, P, P, P, P, P, I, P],
     "csmae_bnrelu_bwd": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "csmae_crop_resize": [L, I, P, P, P, P],
     "csmae_mask_sort": [L, I, I, P, P, P, P, P, P],

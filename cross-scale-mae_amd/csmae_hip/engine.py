@@ -1,0 +1,414 @@
+"""Host-side step engine: sequences the HIP kernels of one Cross-Scale MAE pre-training step.
+
+Mirrors (by behaviour, not by structure) `models_mae/MAE_ViT_Baseline.forward_encoder/_decoder/forward`
+(MAE_ViT_Baseline.py:243-320), `MAE_ViT_MsLd.forward` (MAE_ViT_MsLd.py:37-77) and the loss heads of
+`MAE_ViT_MsLd{Le,Cd,LeCd,CeCd}.py`, but MI355X-first:
+
+* the two views (original + crop) are run as ONE batch of 2N samples through shared weights;
+* patch-embed runs only on the kept 25 % of patches (same per-token arithmetic);
+* all parameters / gradients / AdamW moments live in flat HBM buffers (one bf16 mirror for the MFMA GEMMs),
+  so the optimizer and the RCCL all-reduce are single-buffer operations;
+* autograd sees one coarse node: `backward()` below is the hand-written reverse pass;
+* every per-step scalar (crop box, upstream gradient) is read by the kernels from device memory, so the
+  whole sequence is hipGraph-capturable.
+
+PyTorch is used for memory, streams and the RNG draws the reference makes (`torch.rand` on the device
+generator for the masking noise, the CPU generator for the crop box — Appendix E5 of SURVEY.md).
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Dict, Optional
+
+import torch
+
+from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, ops
+
+_FROZEN = ("encoder_pos_embed", "decoder_pos_embed")
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class FlatParams:
+    """All nn.Parameters of a model re-homed into one fp32 buffer (8-element aligned slots) + flat grad buffer."""
+
+    def __init__(self, module: torch.nn.Module, device):
+        self.names, self.slots = [], {}
+        off = 0
+        params = list(module.named_parameters())
+        for name, p in params:
+            n = p.numel()
+            self.slots[name] = (off, n, tuple(p.shape))
+            self.names.append(name)
+            off += _round_up(n, 8)
+        self.total = off
+        self.p = torch.zeros(off, device=device, dtype=torch.float32)
+        self.g = torch.zeros(off, device=device, dtype=torch.float32)
+        self.w_lp: Optional[torch.Tensor] = None  # bf16 mirror (allocated on demand)
+        self.params = dict(params)
+        with torch.no_grad():
+            for name, p in params:
+                o, n, shape = self.slots[name]
+                view = self.p[o:o + n].view(shape)
+                view.copy_(p.data.to(device))
+                p.data = view
+        self.grad_views = {name: self.g[o:o + n].view(shape) for name, (o, n, shape) in self.slots.items()}
+        self._by_id = {id(p): name for name, p in params}
+        FlatParams._registry.append(weakref.ref(self))
+
+    _registry = []
+
+    @classmethod
+    def owner_of(cls, p):
+        """The live flat buffer a parameter is homed in (None if it is not)."""
+        alive = []
+        found = None
+        for ref in cls._registry:
+            f = ref()
+            if f is None:
+                continue
+            alive.append(ref)
+            name = f._by_id.get(id(p))
+            if name is not None and p.is_cuda and p.data_ptr() == f.p.data_ptr() + f.slots[name][0] * 4:
+                found = f
+        cls._registry[:] = alive
+        return found
+
+    def slot_of(self, p):
+        return self.slots[self._by_id[id(p)]]
+
+    def still_homed(self) -> bool:
+        first = self.params[self.names[0]]
+        return first.data_ptr() == self.p.data_ptr() + self.slots[self.names[0]][0] * 4 and first.is_cuda
+
+    def P(self, name):
+        o, n, shape = self.slots[name]
+        return self.p[o:o + n].view(shape)
+
+    def G(self, name):
+        return self.grad_views[name]
+
+    def lp(self, name, rows=None):
+        o, n, shape = self.slots[name]
+        t = self.w_lp[o:o + n]
+        return t.view(shape[0], -1) if len(shape) > 1 else t
+
+
+class Workspace:
+    """Per-(batch, keep) activation arena.  Everything the backward needs is kept (12 GB at ViT-B/N=128 — 4 % of HBM)."""
+
+    def __init__(self, eng: "Engine", N: int, keep: int):
+        c, dev, T = eng.cfg, eng.device, eng.act_dtype
+        self.N, self.keep = N, keep
+        V = eng.views
+        B2 = V * N
+        self.B2, self.Te, self.Td = B2, keep + 1, c["L"] + 1
+        Me, Md = B2 * self.Te, B2 * self.Td
+        self.Me, self.Md = Me, Md
+        D, Dd, L, Pp = c["D"], c["Dd"], c["L"], eng.Pp
+        f32 = dict(device=dev, dtype=torch.float32)
+        lp = dict(device=dev, dtype=T)
+        E = torch.empty
+        self.imgs_crop = E(N, c["C"], c["S"], c["S"], **f32) if V == 2 else None
+        self.box = torch.zeros(4, device=dev, dtype=torch.int32)
+        self.noise = E(B2, L, **f32)
+        self.ids_restore = E(B2, L, device=dev, dtype=torch.long)
+        self.mask = E(B2, L, **f32)
+        self.ids_keep = E(B2, max(keep, 1), device=dev, dtype=torch.int32)
+        self.a_pe = E(B2 * max(keep, 1), Pp, **lp)
+        self.tok = E(B2 * max(keep, 1), D, **f32)
+
+        def stack(nl, M, Dm, H):
+            return dict(x=E(nl + 1, M, Dm, **f32), xm=E(nl, M, Dm, **f32), y1=E(nl, M, Dm, **lp), y2=E(nl, M, Dm, **lp),
+                        qkv=E(nl, M, 3 * Dm, **lp), o=E(nl, M, Dm, **lp), pre=E(nl, M, 4 * Dm, **lp), h=E(nl, M, 4 * Dm, **lp),
+                        st=E(nl, 4, M, **f32), lse=E(nl, M * H, **f32))
+        self.enc = stack(c["Ne"], Me, D, c["He"])
+        self.dec = stack(c["Nd"], Md, Dd, c["Hd"])
+        self.lat_lp = E(Me, D, **lp) if T != torch.float32 else None
+        self.z = E(Me, Dd, **f32)
+        self.emb_lp = E(Md, Dd, **lp)
+        self.emb32 = E(Md, Dd, **f32)
+        self.dn_st = E(2, Md, **f32)
+        self.pred = E(Md, c["P"], **f32)
+        self.rowloss = E(B2 * L, **f32)
+        self.minmax = E(4, **f32)
+        self.mm_scratch = E(B2 * L * 2, **f32) if c["loss"] == "bce" else None
+        self.losses = torch.zeros(8, **f32)
+        if eng.has_pred:
+            Hp = c["Hp"]
+            self.pin = E(N * L, Dd, **lp)
+            self.u = E(N * L, Hp, **lp)
+            self.r = E(N * L, Hp, **lp)
+            self.v = E(N * L, Dd, **f32)
+            self.bn_st = E(2, L, **f32)
+            self.cd_partial = E(512, **f32)
+            self.dv = E(N * L, Dd, **lp)
+            self.dr = E(N * L, Hp, **lp)
+            self.dpin = E(N * L, Dd, **lp)
+        if eng.has_ce:
+            self.zc = E(B2, D, **f32)
+            self.inv_norm = E(B2, **f32)
+            self.E = E(B2, B2, **f32)
+            self.neg = E(B2, **f32)
+            self.ce_rowloss = E(B2, **f32)
+            self.dpool = E(B2, D, **f32)
+        if eng.has_le:
+            self.e_partial = E(512, **f32)
+        # backward scratch (shared by all layers)
+        Mmax_e, Mmax_d = Me, Md
+        self.gout = torch.ones(1, **f32)
+        self.dres_e = E(Mmax_e, D, **f32)
+        self.dres_e_lp = E(Mmax_e, D, **lp)
+        self.dres_d = E(Mmax_d, Dd, **f32)
+        self.dres_d_lp = E(Mmax_d, Dd, **lp)
+        big = max(Me * 4 * D, Md * 4 * Dd)
+        self.t4 = E(big, **lp)      # dpre
+        self.t3 = E(max(Me * 3 * D, Md * 3 * Dd), **lp)  # dqkv
+        self.t1 = E(max(Me * D, Md * Dd), **lp)          # dy / do
+        self.dpred_lp = E(Md, Pp, **lp)
+        self.demb = E(Md, Dd, **f32)
+        self.dz_lp = E(Me, Dd, **lp)
+        self.dtok_lp = E(B2 * max(keep, 1), D, **lp)
+
+
+class Engine:
+    def __init__(self, module: torch.nn.Module, flat: FlatParams, cfg: dict, act_dtype=torch.bfloat16):
+        self.module, self.cfg, self.device = module, cfg, flat.p.device
+        if self.device.type != "cuda":
+            raise RuntimeError("csmae_hip.Engine needs an MI355X (device 'cuda'): there is no CPU or eager fallback on the product path")
+        self.act_dtype = act_dtype
+        self.T = BF16 if act_dtype == torch.bfloat16 else F32
+        v = cfg["variant"]
+        self.views = 1 if v == "Baseline" else 2
+        self.has_pred = v in ("MsLdCd", "MsLdLeCd", "MsLdCeCd")
+        self.has_ce = v == "MsLdCeCd"
+        self.has_le = v in ("MsLdLe", "MsLdLeCd")
+        self.Pp = _round_up(cfg["P"], 8) if self.T == BF16 else cfg["P"]
+        self.flat = flat
+        if self.T == BF16:
+            if flat.w_lp is None:
+                flat.w_lp = torch.zeros(flat.total, device=self.device, dtype=torch.bfloat16)
+            if self.Pp != cfg["P"]:  # P = p*p*C not a multiple of 8 (ViT-H/14): zero-padded private copies of the two P-shaped weights
+                self.w_pe_pad = torch.zeros(cfg["D"], self.Pp, device=self.device, dtype=torch.bfloat16)
+                self.w_pred_pad = torch.zeros(self.Pp, cfg["Dd"], device=self.device, dtype=torch.bfloat16)
+        self.ws: Optional[Workspace] = None
+        self.lp_fresh = False
+        self._saved = None
+
+    # ------------------------------------------------------------------ helpers
+    def W(self, name):
+        """GEMM-operand view of a weight: bf16 mirror in throughput mode, the fp32 master in parity mode."""
+        if self.T == BF16:
+            return self.flat.lp(name)
+        t = self.flat.P(name)
+        return t.view(t.shape[0], -1) if t.dim() > 1 else t
+
+    def _refresh_lp(self):
+        if self.T == BF16 and not self.lp_fresh:
+            ops.cast_bf16(self.flat.p, self.flat.w_lp)
+            if self.Pp != self.cfg["P"]:
+                P = self.cfg["P"]
+                self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
+                self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
+            self.lp_fresh = True
+
+    def _w_pe(self):
+        if self.T == BF16 and self.Pp != self.cfg["P"]:
+            return self.w_pe_pad
+        return self.W("patch_embed.proj.weight")
+
+    def _w_pred(self):
+        if self.T == BF16 and self.Pp != self.cfg["P"]:
+            return self.w_pred_pad
+        return self.W("decoder_pred.weight")
+
+    @staticmethod
+    def _splitk(m_out, n_out, k_red, tile, ktile):
+        tiles = math.ceil(m_out / tile) * math.ceil(n_out / tile)
+        kt = math.ceil(k_red / ktile)
+        want = max(1, 768 // tiles)
+        return max(1, min(want, kt // 4 if kt >= 8 else 1))
+
+    def _dw(self, dy, x, name):
+        """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored)."""
+        gw = self.flat.G(name + ".weight")
+        gw2 = gw.view(gw.shape[0], -1)
+        tile, kt = (128, 64) if self.T == BF16 else (64, 16)
+        sk = self._splitk(gw2.shape[0], gw2.shape[1], dy.shape[0], tile, kt)
+        dyv, xv = dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]]
+        ops.gemm(dyv, xv, gw2, trans_a=True, trans_b=True, epilogue=EPI_ATOMIC, splitk=sk, st=self.st)
+        ops.colsum(dyv, self.flat.G(name + ".bias"), st=self.st)
+
+    # ------------------------------------------------------------------ transformer block
+    def _block_fwd(self, S, i, pre, M, Dm, H, B2, T):
+        P, st = self.flat.P, self.st
+        x_in, x_mid, x_out = S["x"][i], S["xm"][i], S["x"][i + 1]
+        stt = S["st"][i]
+        lse = S["lse"][i][: B2 * H * T]
+        ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), S["y1"][i], stt[0], stt[1], st=st)
+        ops.gemm(S["y1"][i], self.W(pre + "attn.qkv.weight"), S["qkv"][i], bias=P(pre + "attn.qkv.bias"), st=st)
+        ops.attn_fwd(S["qkv"][i], S["o"][i], lse, B2, T, H, Dm // H, st=st)
+        ops.gemm(S["o"][i], self.W(pre + "attn.proj.weight"), x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st)
+        ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), S["y2"][i], stt[2], stt[3], st=st)
+        ops.gemm(S["y2"][i], self.W(pre + "mlp.fc1.weight"), S["h"][i], bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=S["pre"][i], st=st)
+        ops.gemm(S["h"][i], self.W(pre + "mlp.fc2.weight"), x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st)
+
+    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, dres_lp):
+        P, G, st, ws = self.flat.P, self.flat.G, self.st, self.ws
+        stt = S["st"][i]
+        lse = S["lse"][i][: B2 * H * T]
+        dpre = ws.t4[: M * 4 * Dm].view(M, 4 * Dm)
+        dqkv = ws.t3[: M * 3 * Dm].view(M, 3 * Dm)
+        t1 = ws.t1[: M * Dm].view(M, Dm)
+        self._dw(dres_lp, S["h"][i], pre + "mlp.fc2")
+        ops.gemm(dres_lp, self.W(pre + "mlp.fc2.weight"), dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st)
+        self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
+        ops.gemm(dpre, self.W(pre + "mlp.fc1.weight"), t1, trans_b=True, st=st)
+        ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, G(pre + "norm2.weight"), G(pre + "norm2.bias"),
+                          dres_in=dres, dx_lp=dres_lp, st=st)
+        self._dw(dres_lp, S["o"][i], pre + "attn.proj")
+        ops.gemm(dres_lp, self.W(pre + "attn.proj.weight"), t1, trans_b=True, st=st)
+        ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
+        self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
+        ops.gemm(dqkv, self.W(pre + "attn.qkv.weight"), t1, trans_b=True, st=st)
+        ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, G(pre + "norm1.weight"), G(pre + "norm1.bias"),
+                          dres_in=dres, dx_lp=dres_lp, st=st)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool):
+        c = self.cfg
+        N = imgs.shape[0]
+        keep = int(c["L"] * (1 - mask_ratio))
+        if keep < 1:
+            raise ValueError(f"mask_ratio={mask_ratio} keeps no patch (L={c['L']})")
+        if self.ws is None or self.ws.N != N or self.ws.keep != keep:
+            self.ws = None
+            self.ws = Workspace(self, N, keep)
+        ws, P = self.ws, self.flat.P
+        self.st = st = ops.stream()
+        B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
+        self._refresh_lp()
+        img0 = imgs
+        img1 = None
+        if self.views == 2:
+            ws.box.copy_(box_host, non_blocking=True)
+            ops.crop_resize(img0, ws.imgs_crop, ws.box, st=st)
+            img1 = ws.imgs_crop
+        ws.noise.copy_(noise)
+        ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
+        ops.patch_gather(img0, img1, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
+        ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
+        ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep, st=st)
+        for i in range(c["Ne"]):
+            self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te)
+        latent = ws.enc["x"][c["Ne"]]
+        if self.T == BF16:
+            ops.cast_bf16(latent, ws.lat_lp, st=st)
+            lat_op = ws.lat_lp
+        else:
+            lat_op = latent
+        ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z, bias=P("decoder_embed.bias"), st=st)
+        ops.unshuffle_fwd(ws.z, P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore, ws.dec["x"][0], B2, L, keep, st=st)
+        for i in range(c["Nd"]):
+            self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td)
+        ops.layernorm_fwd(ws.dec["x"][c["Nd"]], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp, ws.dn_st[0], ws.dn_st[1], y32=ws.emb32, st=st)
+        emb_op = ws.emb_lp
+        ops.gemm(emb_op, self._w_pred()[: c["P"]], ws.pred, bias=P("decoder_pred.bias"), st=st)
+        kind, npx = c["loss"], c["norm_pix"]
+        mm = None
+        if kind == "bce":
+            ops.target_minmax(img0, img1, ws.mm_scratch, ws.minmax, B2, N, c["C"], c["S"], c["p"], npx, st=st)
+            mm = ws.minmax
+        ops.recon_loss_fwd(kind, npx, img0, img1, ws.pred, mm, ws.rowloss, B2, N, c["C"], c["S"], c["p"], st=st)
+        kw = {}
+        if self.has_pred:
+            kcd = c["loss_cd"]
+            bn = "predictor.1."
+            mod = self.module.predictor[1]
+            ops.rows_gather(ws.emb32, ws.pin, L, Td, N * Td + 1, st=st)
+            ops.gemm(ws.pin, self.W("predictor.0.weight"), ws.u, bias=P("predictor.0.bias"), st=st)
+            ops.bnrelu_fwd(ws.u, P(bn + "weight"), P(bn + "bias"), ws.r, ws.bn_st[0], ws.bn_st[1], N, L, mod.running_mean, mod.running_var,
+                           mod.num_batches_tracked, eps=mod.eps, momentum=mod.momentum, training=training, st=st)
+            ops.gemm(ws.r, self.W("predictor.3.weight"), ws.v, bias=P("predictor.3.bias"), st=st)
+            ops.pair_loss_fwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.cd_partial, st=st)
+            kw.update(cd_partial=ws.cd_partial, cd_scale=self._pair_scale(kcd, N * L, Dd))
+        if self.has_le:
+            ke = c["loss_e"]
+            ops.pair_loss_fwd(ke, N * Te, D, latent, (N * Te, 0, N * Te), latent, (N * Te, 0, 0), ws.e_partial, st=st)
+            kw.update(e_partial=ws.e_partial, e_scale=self._pair_scale(ke, N * Te, D))
+        if self.has_ce:
+            ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
+            kw.update(ce_rowloss=ws.ce_rowloss, ce_rows=B2)
+        rscale = 0.5 if (self.views == 2 and c["reduction"] == "mean") else 1.0
+        ops.loss_finalize(N * L, self.views, ws.rowloss, ws.mask, rscale, ws.losses, st=st, **kw)
+        self._saved = dict(img0=img0, img1=img1, N=N, keep=keep, mm=mm, rscale=rscale)
+        return ws
+
+    @staticmethod
+    def _pair_scale(kind, rows, D):
+        return 1.0 / (rows * D) if kind in ("mse", "mae") else 1.0 / rows
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, gout: torch.Tensor, accumulate: bool):
+        c, ws, sv = self.cfg, self.ws, self._saved
+        if sv is None:
+            raise RuntimeError("backward() called without a preceding forward()")
+        P, G = self.flat.P, self.flat.G
+        self.st = st = ops.stream()
+        N, keep = sv["N"], sv["keep"]
+        B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
+        if not accumulate:
+            self.flat.g.zero_()
+        ws.gout.copy_(gout.reshape(1).to(torch.float32))
+        kind, npx = c["loss"], c["norm_pix"]
+        # reconstruction head
+        ops.recon_loss_bwd(kind, npx, sv["img0"], sv["img1"], ws.pred, sv["mm"], ws.mask, ws.losses, ws.gout, sv["rscale"], ws.dpred_lp,
+                           B2, N, c["C"], c["S"], c["p"], st=st)
+        self._dw(ws.dpred_lp, ws.emb_lp, "decoder_pred")
+        ops.gemm(ws.dpred_lp, self._w_pred(), ws.demb, trans_b=True, st=st)
+        if self.has_pred:
+            kcd = c["loss_cd"]
+            bn = "predictor.1."
+            ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
+                              da_lp=ws.dv, dt_acc=ws.demb, st=st)
+            self._dw(ws.dv, ws.r, "predictor.3")
+            ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=st)
+            ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=st)
+            self._dw(ws.dr, ws.pin, "predictor.0")
+            ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=st)
+            ops.rows_scatter_add(ws.dpin, ws.demb, L, Td, N * Td + 1, st=st)
+        # decoder
+        ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d,
+                          G("decoder_norm.weight"), G("decoder_norm.bias"), dx_lp=ws.dres_d_lp, st=st)
+        for i in reversed(range(c["Nd"])):
+            self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp)
+        ops.unshuffle_bwd(ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
+        lat_op = ws.lat_lp if self.T == BF16 else ws.enc["x"][c["Ne"]]
+        self._dw(ws.dz_lp, lat_op, "decoder_embed")
+        ops.gemm(ws.dz_lp, self.W("decoder_embed.weight"), ws.dres_e, trans_b=True, st=st)
+        latent = ws.enc["x"][c["Ne"]]
+        if self.has_le:
+            ke = c["loss_e"]
+            ops.pair_loss_bwd(ke, N * Te, D, latent, (N * Te, 0, N * Te), latent, (N * Te, 0, 0), ws.gout, self._pair_scale(ke, N * Te, D),
+                              da_acc=ws.dres_e, dt_acc=ws.dres_e, lp_dtype=self.T, st=st)
+        dpool = None
+        if self.has_ce:
+            ops.ntxent_bwd(ws.zc, ws.inv_norm, ws.E, ws.neg, ws.gout, ws.dpool, N, st=st)
+            dpool = ws.dpool
+        ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp, B2, Te, st=st)
+        for i in reversed(range(c["Ne"])):
+            self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, ws.dres_e, ws.dres_e_lp)
+        ops.embed_assemble_bwd(ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
+        gw = G("patch_embed.proj.weight").view(D, c["P"])
+        tile, kt = (128, 64) if self.T == BF16 else (64, 16)
+        ops.gemm(ws.dtok_lp, ws.a_pe[:, : c["P"]], gw, trans_a=True, trans_b=True, epilogue=EPI_ATOMIC,
+                 splitk=self._splitk(D, c["P"], ws.dtok_lp.shape[0], tile, kt), st=st)
+        ops.colsum(ws.dtok_lp, G("patch_embed.proj.bias"), st=st)
+        # hand the gradient views to autograd's .grad slots (frozen and unused parameters keep None — encoder_norm: E1)
+        for name, p in self.flat.params.items():
+            if p.requires_grad and not name.startswith("encoder_norm."):
+                p.grad = self.flat.grad_views[name]
+

@@ -59,9 +59,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx_out, dgamma, dbeta, dres_in=None,
                                      _p(dgamma), _p(dbeta), st if st is not None else stream()), "csmae_layernorm_bwd")
 
 
-def bnrelu_fwd(u, gamma, beta, r, mean, rstd, N, L, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, st=None):
+def bnrelu_fwd(u, gamma, beta, r, mean, rstd, N, L, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, training=True, st=None):
     check(load().csmae_bnrelu_fwd(dt(u), N, L, u.shape[1], _p(u), _p(gamma), _p(beta), eps, momentum, _p(r), _p(mean), _p(rstd),
-                                  _p(running_mean), _p(running_var), _p(nbt), st if st is not None else stream()), "csmae_bnrelu_fwd")
+                                  _p(running_mean), _p(running_var), _p(nbt), int(training), st if st is not None else stream()), "csmae_bnrelu_fwd")
 
 
 def bnrelu_bwd(u, dr, gamma, beta, mean, rstd, du, dgamma, dbeta, N, L, st=None):

@@ -279,8 +279,9 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
   if (dtype == CSMAE_BF16) {
     CSMAE_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && K % 8 == 0, "csmae_gemm(bf16): lda, ldb, K must be multiples of 8 (lda=%lld ldb=%lld K=%lld)", lda, ldb, K);
     CSMAE_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "csmae_gemm(bf16): A, B, C must be 16-byte aligned");
-    CSMAE_REQUIRE(!transA || M % 8 == 0, "csmae_gemm(bf16): transposed A needs M %% 8 == 0");
-    CSMAE_REQUIRE(!transB || N % 8 == 0, "csmae_gemm(bf16): transposed B needs N %% 8 == 0");
+    // K-strided operands are fetched in 8-column chunks: the row allocation must cover the rounded-up width
+    CSMAE_REQUIRE(!transA || lda >= (M + 7) / 8 * 8, "csmae_gemm(bf16): transposed A needs lda >= roundup8(M)");
+    CSMAE_REQUIRE(!transB || ldb >= (N + 7) / 8 * 8, "csmae_gemm(bf16): transposed B needs ldb >= roundup8(N)");
     long long abytes = (transA ? K : M) * lda * 2, bbytes = (transB ? K : N) * ldb * 2;
     CSMAE_REQUIRE(abytes < 0xFFFFFFF0ll && bbytes < 0xFFFFFFF0ll, "csmae_gemm(bf16): operand larger than 4 GiB");
     p.a_bytes = (unsigned)abytes; p.b_bytes = (unsigned)bbytes;

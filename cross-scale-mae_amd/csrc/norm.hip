@@ -161,10 +161,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(int N, int L, int Hp, const T* __restrict__ u, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, float momentum, T* __restrict__ r,
                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
-                                                         float* __restrict__ run_var, long long* __restrict__ nbt) {
+                                                         float* __restrict__ run_var, long long* __restrict__ nbt, int training) {
   __shared__ float red[32];
   const int l = blockIdx.x, hv = Hp >> 2;
   const long long cnt = (long long)N * Hp;
+  if (!training) {  // eval(): normalise with the running statistics, touch nothing
+    const float mu = run_mean[l], rs = rsqrtf(run_var[l] + eps), gm = gamma[l], bt = beta[l];
+    for (long long e = threadIdx.x; e < (long long)N * hv; e += blockDim.x) {
+      long long n = e / hv; int c = (int)(e - n * hv);
+      f4_t v = (ld4<T>(u + (n * L + l) * Hp + c * 4) - mu) * rs * gm + bt;
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      st4<T>(r + (n * L + l) * Hp + c * 4, v);
+    }
+    if (threadIdx.x == 0) { mean[l] = mu; rstd[l] = rs; }
+    return;
+  }
   float s = 0.f;
   for (long long e = threadIdx.x; e < (long long)N * hv; e += blockDim.x) {
     long long n = e / hv; int c = (int)(e - n * hv);
@@ -228,12 +239,13 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(int N, int L, int Hp, c
 
 extern "C" int csmae_bnrelu_fwd(int dtype, int N, int L, int Hp, const void* u, const float* gamma, const float* beta, float eps,
                                 float momentum, void* r, float* mean, float* rstd, float* running_mean, float* running_var,
-                                long long* num_batches_tracked, void* stream) {
+                                long long* num_batches_tracked, int training, void* stream) {
   CSMAE_REQUIRE(N > 0 && L > 0 && Hp > 0 && Hp % 4 == 0, "csmae_bnrelu_fwd: bad geometry N=%d L=%d Hp=%d", N, L, Hp);
-  CSMAE_REQUIRE((long long)N * Hp > 1, "csmae_bnrelu_fwd: need more than one value per channel (torch raises the same)");
+  CSMAE_REQUIRE(!training || (long long)N * Hp > 1, "csmae_bnrelu_fwd: need more than one value per channel (torch raises the same)");
+  CSMAE_REQUIRE(training || (running_mean && running_var), "csmae_bnrelu_fwd: eval mode needs running statistics");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t>), dim3(L), dim3(256), 0, st, N, L, Hp, (const bf16_t*)u, gamma, beta, eps, momentum, (bf16_t*)r, mean, rstd, running_mean, running_var, num_batches_tracked);
-  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_fwd_kernel<float>), dim3(L), dim3(256), 0, st, N, L, Hp, (const float*)u, gamma, beta, eps, momentum, (float*)r, mean, rstd, running_mean, running_var, num_batches_tracked);
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t>), dim3(L), dim3(256), 0, st, N, L, Hp, (const bf16_t*)u, gamma, beta, eps, momentum, (bf16_t*)r, mean, rstd, running_mean, running_var, num_batches_tracked, training);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_fwd_kernel<float>), dim3(L), dim3(256), 0, st, N, L, Hp, (const float*)u, gamma, beta, eps, momentum, (float*)r, mean, rstd, running_mean, running_var, num_batches_tracked, training);
   else { csmae_set_error("csmae_bnrelu_fwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_bnrelu_fwd");
 }

@@ -1,0 +1,175 @@
+"""MAE ViT (reference models_mae/MAE_ViT_Baseline.py): same constructor signature, attributes, parameter names,
+registration order and seeded initialisation; forward/backward run on the MI355X through csmae_hip.Engine."""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from util.pos_embed import get_2d_sincos_pos_embed
+
+from ._holders import Block, PatchEmbed
+from .MAE_ViT_Shared import MAE_ViT_Shared
+
+
+class _StepFn(torch.autograd.Function):
+    """One coarse autograd node for the whole step: forward = HIP forward, backward = hand-written HIP reverse pass that
+    writes straight into the flat gradient buffer (parameter grads are attached there, not returned)."""
+
+    @staticmethod
+    def forward(ctx, model, engine, imgs, mask_ratio, noise, box, *params):
+        ws = engine.forward(imgs, mask_ratio, noise, box, model.training)
+        ctx.model, ctx.engine = model, engine
+        ctx.set_materialize_grads(False)
+        outs = model._outputs(engine, ws, imgs.shape[0])
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, gloss, gpred, *rest):
+        if gpred is not None:
+            raise NotImplementedError("gradients w.r.t. the returned prediction are not supported: only the loss is differentiable")
+        if gloss is not None:
+            model = ctx.model
+            grads = [p.grad for p in model.parameters() if p.requires_grad]
+            ctx.engine.backward(gloss, accumulate=any(g is not None for g in grads))
+        return (None,) * (6 + len(ctx.engine.flat.params))
+
+
+class MAE_ViT_Baseline(MAE_ViT_Shared):
+    """Masked Autoencoder with VisionTransformer backbone"""
+
+    VARIANT = "Baseline"
+
+    def __init__(self, input_size=128, input_channels=3, patch_size=16, mask_ratio=0.75, dim_model=1024,
+                 encoder_num_layers=24, encoder_num_heads=16, decoder_embed_dim=512, decoder_num_layers=8, decoder_num_heads=16,
+                 residual_norm_style="post", residual_dropout=0.0, ffn_name="MLP", ffn_activation="gelu", ffn_ratio=4, ffn_dropout=0.0,
+                 attn_name="scaled_dot_product", attn_dropout=0.0, norm_layer=partial(nn.LayerNorm, eps=1e-6), use_xformers=False,
+                 device=None, **kwargs):
+        super().__init__(**kwargs)
+        self.input_size = input_size
+        self.input_channels = input_channels
+        self.patch_size = int(patch_size)
+        self.dim_model = dim_model
+        self.decoder_embed_dim = decoder_embed_dim
+        self.mask_ratio = mask_ratio
+        self.use_xformers = use_xformers
+        self.device = device
+        assert input_size % self.patch_size == 0
+        if use_xformers:
+            raise NotImplementedError("use_xformers=True selects xFormers' post-norm block zoo (MAE_ViT_Baseline.py:94-157): a different "
+                                      "network built on an un-vendored package, outside the MI355X hot-path scope (SURVEY.md §2 row 3)")
+        assert attn_name == "scaled_dot_product", f"Attention {attn_name} not supported (timm path uses scaled_dot_product)"
+        assert ffn_name == "MLP", f"Feedforward {ffn_name} not supported (timm path uses MLP)"
+        assert ffn_activation == "gelu", f"Feedforward activation {ffn_activation} not supported (timm path uses gelu)"
+        if residual_dropout or ffn_dropout or attn_dropout:
+            raise NotImplementedError("dropout / drop-path > 0 is not implemented on the MI355X path (reference defaults are 0)")
+        assert dim_model % encoder_num_heads == 0 and decoder_embed_dim % decoder_num_heads == 0
+        self._geom = dict(He=encoder_num_heads, Ne=encoder_num_layers, Hd=decoder_num_heads, Nd=decoder_num_layers, ffn_ratio=ffn_ratio)
+        if ffn_ratio != 4:
+            raise NotImplementedError("ffn_ratio != 4 is not wired on the MI355X path")
+
+        self.patch_embed = PatchEmbed(input_size, self.patch_size, input_channels, dim_model)
+        self.num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim_model))
+        self.encoder_pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, dim_model), requires_grad=False)
+        self.decoder_embed = nn.Linear(dim_model, decoder_embed_dim, bias=True)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, decoder_embed_dim), requires_grad=False)
+        self.encoder = nn.ModuleList([Block(dim_model, encoder_num_heads, ffn_ratio, norm_layer) for _ in range(encoder_num_layers)])
+        self.decoder = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, ffn_ratio, norm_layer) for _ in range(decoder_num_layers)])
+        self.decoder_pred = nn.Linear(decoder_embed_dim, self.patch_size ** 2 * input_channels, bias=True)
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        self.encoder_norm = norm_layer(dim_model)  # kept for checkpoint compatibility: its output is discarded (MAE_ViT_Baseline.py:264)
+        self.initialize_weights()
+        self.compute_dtype = None  # None: bf16 MFMA under torch autocast, exact fp32 otherwise; or force torch.bfloat16 / torch.float32
+        self._flat = None
+        self._engines = {}
+        self._test_draws = None
+
+    # ---- MAE_ViT_Baseline.py:201-241
+    def initialize_weights(self):
+        grid = int(self.patch_embed.num_patches ** 0.5)
+        for pe in (self.encoder_pos_embed, self.decoder_pos_embed):
+            pe.data.copy_(torch.from_numpy(get_2d_sincos_pos_embed(pe.shape[-1], grid, cls_token=True)).float().unsqueeze(0))
+        w = self.patch_embed.proj.weight.data
+        torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        torch.nn.init.normal_(self.cls_token, std=0.02)
+        torch.nn.init.normal_(self.mask_token, std=0.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ---- engine plumbing
+    def _cfg(self):
+        g = self._geom
+        p, C = self.patch_size, self.input_channels
+        G = self.input_size // p
+        return dict(S=self.input_size, C=C, p=p, G=G, L=G * G, P=p * p * C, D=self.dim_model, He=g["He"], Ne=g["Ne"],
+                    Dd=self.decoder_embed_dim, Hd=g["Hd"], Nd=g["Nd"], Hp=getattr(self, "predictor_hidden_size", 0),
+                    loss=self.loss, norm_pix=bool(self.norm_pix_loss), reduction=getattr(self, "ms_decoder_loss_reduction", "sum"),
+                    loss_cd=getattr(self, "loss_cd", self.loss), loss_e=getattr(self, "loss_e", self.loss), variant=self.VARIANT)
+
+    def _engine(self, imgs):
+        from csmae_hip.engine import Engine, FlatParams
+        if not imgs.is_cuda:
+            raise RuntimeError("this model runs only on an MI355X: move the model and the batch to 'cuda' (there is no CPU fallback; "
+                               "the CPU restatement lives in oracle/ and is test infrastructure)")
+        first = next(self.parameters())
+        if not first.is_cuda:
+            raise RuntimeError("model parameters are on the CPU: call model.to('cuda') first")
+        if self._flat is None or not self._flat.still_homed():
+            self._flat = FlatParams(self, first.device)
+            self._engines = {}
+        dtype = self.compute_dtype
+        if dtype is None:
+            dtype = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        if dtype not in self._engines:
+            self._engines[dtype] = Engine(self, self._flat, self._cfg(), dtype)
+        eng = self._engines[dtype]
+        eng.lp_fresh = False  # parameters may have been stepped / loaded since the last forward: refresh the bf16 mirror
+        return eng
+
+    def _draw(self, imgs, mask_ratio, mask_seed, consistent_mask=False):
+        """The reference's RNG draws, in its order (MAE_ViT_Baseline.py:301-302,251 -> MAE_ViT_Shared.py:66)."""
+        N, L = imgs.shape[0], self.num_patches
+        hook, self._test_draws = self._test_draws, None
+        if mask_seed is not None:
+            torch.manual_seed(mask_seed)
+        noise = hook["noise"][0].to(imgs.device) if hook else torch.rand(N, L, device=imgs.device)
+        return noise, None
+
+    def _outputs(self, eng, ws, N):
+        c = eng.cfg
+        pred = ws.pred.view(ws.B2, ws.Td, c["P"])
+        lat = ws.enc["x"][c["Ne"]].view(ws.B2, ws.Te, c["D"])
+        emb = ws.emb32.view(ws.B2, ws.Td, c["Dd"])
+        return (ws.losses[0].clone(), pred[:N, 1:, :], ws.mask[:N], lat[:N], emb[:N])
+
+    def _run(self, imgs, mask_ratio, noise, box):
+        if imgs.dim() != 4 or imgs.shape[1] != self.input_channels or imgs.shape[2] != self.input_size or imgs.shape[3] != self.input_size:
+            raise AssertionError(f"input {tuple(imgs.shape)} does not match (N, {self.input_channels}, {self.input_size}, {self.input_size})")
+        imgs = imgs.contiguous().float()
+        eng = self._engine(imgs)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _StepFn.apply(self, eng, imgs, mask_ratio, noise, box, *self.parameters())
+        ws = eng.forward(imgs, mask_ratio, noise, box, self.training)
+        return self._outputs(eng, ws, imgs.shape[0])
+
+    # ---- public API (MAE_ViT_Baseline.py:299-320)
+    def forward(self, imgs, mask_ratio=0.75, mask_seed=None, return_embeds=False):
+        noise, box = self._draw(imgs, mask_ratio, mask_seed)
+        loss, pred, mask, enc, dec = self._run(imgs, mask_ratio, noise, box)
+        return (loss, pred, mask) if not return_embeds else (loss, pred, mask, enc, dec)
+
+    def forward_encoder(self, x, mask_ratio):
+        raise NotImplementedError("stand-alone forward_encoder is not exposed on the MI355X path; call the model (return_embeds=True)")
+
+    def forward_decoder(self, x, ids_restore):
+        raise NotImplementedError("stand-alone forward_decoder is not exposed on the MI355X path; call the model (return_embeds=True)")

@@ -1,0 +1,56 @@
+"""Shared base of the MAE family (reference models_mae/MAE_ViT_Shared.py): loss selection, patchify helpers,
+random_masking.  The step itself runs in csmae_hip.Engine (HIP); helpers here are layout/API surface only."""
+import torch
+import torch.nn as nn
+
+SUPPORTED_LOSSES = ("mse", "l2", "mae", "l1", "bce")
+OUT_OF_SCOPE_LOSSES = ("ssim", "ms_ssim", "mse_ssim", "mse_ms_ssim")
+
+
+def check_loss(name, what="loss"):
+    name = name.lower()
+    if name in OUT_OF_SCOPE_LOSSES:
+        raise NotImplementedError(f"{what}={name!r}: the SSIM family needs the un-vendored pytorch_msssim package and is outside the "
+                                  "MI355X hot-path scope (SURVEY.md §2 row 2 / §8 f-4)")
+    if name not in SUPPORTED_LOSSES:
+        raise AttributeError(f"forward_loss_{name}")  # what getattr() raises in the reference (MAE_ViT_Shared.py:19)
+    return name
+
+
+class MAE_ViT_Shared(nn.Module):
+    def __init__(self, norm_pix_loss=False, loss="mse", **kwargs):
+        super().__init__()
+        self.loss = check_loss(loss)
+        self.norm_pix_loss = norm_pix_loss
+
+    # ---- layout helpers (MAE_ViT_Shared.py:24-55): "nchpwq->nhwpqc" and back
+    def patchify(self, imgs, p, c):
+        assert imgs.shape[2] == imgs.shape[3] and imgs.shape[2] % p == 0
+        n, g = imgs.shape[0], imgs.shape[2] // p
+        return imgs.reshape(n, c, g, p, g, p).permute(0, 2, 4, 3, 5, 1).reshape(n, g * g, p * p * c)
+
+    def unpatchify(self, x, p, c):
+        g = int(x.shape[1] ** 0.5)
+        assert g * g == x.shape[1]
+        return x.reshape(x.shape[0], g, g, p, p, c).permute(0, 5, 1, 3, 2, 4).reshape(x.shape[0], c, g * p, g * p)
+
+    def random_masking(self, x, mask_ratio):
+        """MAE_ViT_Shared.py:57-84.  Indices come from the HIP rank-sort (stable ascending == argsort on tie-free rows);
+        the row gather of this stand-alone helper is a torch index op (inside the step it is fused into patch_gather)."""
+        from csmae_hip import ops
+        N, L, D = x.shape
+        keep = int(L * (1 - mask_ratio))
+        noise = torch.rand(N, L, device=x.device)
+        ids_restore = torch.empty(N, L, device=x.device, dtype=torch.long)
+        mask = torch.empty(N, L, device=x.device)
+        ids_keep = torch.empty(N, max(keep, 1), device=x.device, dtype=torch.int32)
+        ops.mask_sort(noise, keep, ids_restore, mask, ids_keep)
+        x_masked = torch.gather(x, 1, ids_keep[:, :keep].long().unsqueeze(-1).expand(-1, -1, D))
+        return x_masked, mask, ids_restore
+
+    def scale_01(self, x):
+        return (x - x.min()) / (x.max() - x.min() + 1.0e-6)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {}

@@ -60,7 +60,7 @@ int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int D, const vo
  * over (sample, feature); updates running stats (momentum, unbiased var) and num_batches_tracked in place. */
 int csmae_bnrelu_fwd(int dtype, int N, int L, int Hp, const void* u, const float* gamma, const float* beta, float eps,
                      float momentum, void* r, float* mean, float* rstd, float* running_mean, float* running_var,
-                     long long* num_batches_tracked, void* stream);
+                     long long* num_batches_tracked, int training, void* stream);
 int csmae_bnrelu_bwd(int dtype, int N, int L, int Hp, const void* u, const void* dr, const float* gamma, const float* beta,
                      const float* mean, const float* rstd, void* du, float* dgamma, float* dbeta, void* stream);
 

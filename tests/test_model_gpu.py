@@ -1,0 +1,288 @@
+"""Step-level parity on the MI355X: the drop-in `models_mae` classes (HIP path, through the C ABI) against
+ (a) the reference's own outputs in tests/golden/ (generated from /root/reference by oracle/gen_golden.py) and
+ (b) the CPU oracle run on the same weights / noise / crop box.
+fp32 mode must meet BASELINE.json's bar: masks bit-exact, every loss term within 1e-4 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+MICRO = dict(dim_model=128, encoder_num_layers=2, encoder_num_heads=2, decoder_embed_dim=64, decoder_num_layers=2, decoder_num_heads=2)
+CLASSES = {"cecd_s0": "MAE_ViT_MsLdCeCd", "msld_s0": "MAE_ViT_MsLd", "msldle_s0": "MAE_ViT_MsLdLe", "msldcd_s0": "MAE_ViT_MsLdCd",
+           "msldlecd_s0": "MAE_ViT_MsLdLeCd", "baseline_s0": "MAE_ViT_Baseline"}
+LOSS_RTOL = 1e-4  # BASELINE.json: reconstruction + contrastive loss within 1e-4 rel fp32
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def micro_sd(d):
+    return {k[3:]: T(d[k]) for k in d.files if k.startswith("sd_")}
+
+
+def build(cls_name, sd, input_size=64, input_channels=3, **kw):
+    import models_mae
+    cls = getattr(models_mae, cls_name)
+    extra = dict(predictor_hidden_size=128) if "Cd" in cls_name or "Ce" in cls_name else {}
+    m = cls(**MICRO, input_size=input_size, input_channels=input_channels, patch_size="16", **extra, **kw)
+    own = m.state_dict()
+    m.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=True)
+    return m.cuda().train()
+
+
+def draws(d, tag, baseline=False):
+    n = [T(d[f"{tag}_noise0"])] + ([] if baseline else [T(d[f"{tag}_noise1"])])
+    return dict(noise=n, box=None if baseline else tuple(int(v) for v in d[f"{tag}_box"]))
+
+
+def oracle_run(sd, variant, imgs, dr, input_size=64, input_channels=3, **cfgkw):
+    import csmae_oracle as O
+    osd = O.trainable_copy(sd)
+    cfg = O.make_cfg(input_size=input_size, input_channels=input_channels, patch_size=16, variant=variant, predictor_hidden_size=128, **MICRO, **cfgkw)
+    bn = None
+    if "predictor.1.running_mean" in osd:
+        bn = dict(running_mean=osd["predictor.1.running_mean"].clone(), running_var=osd["predictor.1.running_var"].clone(),
+                  num_batches_tracked=osd["predictor.1.num_batches_tracked"].clone())
+    out = O.forward(osd, cfg, imgs, dr["noise"][0], dr["noise"][1] if len(dr["noise"]) > 1 else None, dr["box"], 0.75, bn)
+    out["loss"].backward()
+    return osd, out
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+
+@pytest.mark.parametrize("tag", list(CLASSES))
+def test_micro_variants_fp32_vs_reference_and_oracle(tag):
+    d = load("model_micro.npz")
+    sd = micro_sd(d)
+    base = tag == "baseline_s0"
+    m = build(CLASSES[tag], sd)
+    imgs = T(d["imgs"])
+    dr = draws(d, tag, base)
+    m._test_draws = dict(dr)
+    out = m(imgs.cuda(), mask_ratio=0.75, return_embeds=True)
+    loss = out[0]
+    eng = m._engines[torch.float32]
+    L = eng.ws.losses.cpu()
+    # (a) the reference's outputs
+    assert rel(loss, d[f"{tag}_loss"]) < LOSS_RTOL, (float(loss), float(d[f"{tag}_loss"]))
+    recon = d[f"{tag}_recon"]
+    assert rel(L[1], recon[0]) < LOSS_RTOL
+    if not base:
+        assert rel(L[2], recon[1]) < LOSS_RTOL
+    for k, idx in (("cd", 3), ("ce", 4), ("e", 5)):
+        if f"{tag}_loss_{k}" in d.files:
+            assert rel(L[idx], d[f"{tag}_loss_{k}"][0]) < LOSS_RTOL, (k, float(L[idx]), d[f"{tag}_loss_{k}"][0])
+    assert np.array_equal(out[2].cpu().numpy(), d[f"{tag}_mask"])  # bit-exact mask
+    np.testing.assert_allclose(out[1][:, :3, :32].detach().cpu().numpy(), d[f"{tag}_pred_head"], rtol=1e-3, atol=2e-5)
+    loss.backward()
+    names = [str(n) for n in d[f"{tag}_gradnames"]]
+    params = dict(m.named_parameters())
+    for n, sq in zip(names, d[f"{tag}_gradsq"]):
+        got = params[n].grad.double().pow(2).sum().item()
+        assert abs(got - sq) <= 2e-3 * sq + 1e-14, (n, got, sq)
+    nograd = sorted(n for n, p in params.items() if p.requires_grad and p.grad is None)
+    assert nograd == sorted(str(n) for n in d[f"{tag}_nograd"])
+    # (b) the oracle on the same inputs: every gradient, elementwise
+    variant = CLASSES[tag].replace("MAE_ViT_", "")
+    osd, oout = oracle_run(sd, variant, imgs, dr)
+    assert rel(loss, oout["loss"]) < 2e-5
+    assert torch.equal(eng.ws.ids_restore[: imgs.shape[0]].cpu(), oout["ids_restore"])
+    for n, p in params.items():
+        if p.grad is None:
+            continue
+        ref = osd[n].grad
+        scale = ref.abs().max().item()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-4 * scale + 1e-9, err_msg=n)
+    if not base:
+        np.testing.assert_allclose(out[3][1].cpu().numpy(), oout["enc_crop"].detach().numpy(), rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(out[4][0].cpu().numpy(), oout["dec_orig"].detach().numpy(), rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(eng.ws.imgs_crop.cpu().numpy(), oout["imgs_crop"].numpy(), rtol=0, atol=5e-6)
+
+
+def test_micro_two_fused_adamw_steps_fp32():
+    from csmae_hip.optim import FusedAdamW, add_weight_decay
+    d = load("model_micro.npz")
+    m = build("MAE_ViT_MsLdCeCd", micro_sd(d))
+    opt = FusedAdamW(add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    imgs = T(d["imgs"]).cuda()
+    for s in range(2):
+        tag = f"cecd_s{s}"
+        m._test_draws = draws(d, tag)
+        opt.zero_grad()
+        loss, _, _ = m(imgs, mask_ratio=0.75)
+        assert rel(loss, d[f"{tag}_loss"]) < LOSS_RTOL, (s, float(loss), float(d[f"{tag}_loss"]))
+        loss.backward()
+        opt.step()
+        params = dict(m.named_parameters())
+        names = [str(n) for n in d[f"{tag}_gradnames"]]
+        sel = [i for i, n in enumerate(names) if not n.endswith("attn.qkv.bias")]  # zero-gradient key biases: see test_oracle_golden
+        got = [params[names[i]].detach().double().sum().item() for i in sel]
+        np.testing.assert_allclose(got, d[f"{tag}_paramsum_after"][sel], rtol=2e-5, atol=2e-4)
+        for k in d.files:
+            if k.startswith(f"{tag}_p_") and not k.endswith("attn.qkv.bias"):
+                np.testing.assert_allclose(params[k[len(tag) + 3:]].detach().cpu().numpy(), d[k], rtol=1e-4, atol=5e-5, err_msg=k)
+        np.testing.assert_allclose(m.predictor[1].running_mean.cpu().numpy(), d[f"{tag}_buf_predictor.1.running_mean"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(m.predictor[1].running_var.cpu().numpy(), d[f"{tag}_buf_predictor.1.running_var"], rtol=1e-4)
+        assert int(m.predictor[1].num_batches_tracked) == s + 1
+    sd = opt.state_dict()  # torch.optim.AdamW layout
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and len(sd["param_groups"]) == 2
+
+
+@pytest.mark.parametrize("loss", ["l2", "mae", "l1", "normpix_mean"])
+def test_loss_options_fp32(loss):
+    d = load("model_micro.npz")
+    kw = dict(loss="mse", norm_pix_loss=True, ms_decoder_loss_reduction="mean") if loss == "normpix_mean" else dict(loss=loss)
+    m = build("MAE_ViT_MsLdCeCd", micro_sd(d), **kw)
+    m._test_draws = draws(d, "cecd_s0")
+    out = m(T(d["imgs"]).cuda())
+    assert rel(out[0], d[f"cecd_{loss}_loss"]) < LOSS_RTOL
+    L = m._engines[torch.float32].ws.losses.cpu()
+    np.testing.assert_allclose(L[1:3].numpy(), d[f"cecd_{loss}_recon"], rtol=LOSS_RTOL)
+    out[0].backward()
+    names = [str(n) for n in d["cecd_s0_gradnames"]]
+    params = dict(m.named_parameters())
+    got = np.array([params[n].grad.double().pow(2).sum().item() for n in names])
+    np.testing.assert_allclose(got, d[f"cecd_{loss}_gradsq"], rtol=5e-3, atol=1e-14)
+
+
+def test_bce_reconstruction_supported_but_bce_cross_decoder_is_not():
+    import csmae_hip
+    d = load("model_micro.npz")
+    m = build("MAE_ViT_MsLd", micro_sd(d), loss="bce")
+    m._test_draws = draws(d, "msld_s0")
+    loss, _, _ = m(T(d["imgs"]).cuda())
+    import csmae_oracle as O
+    osd, oout = oracle_run(micro_sd(d), "MsLd", T(d["imgs"]), draws(d, "msld_s0"), loss="bce")
+    assert rel(loss, oout["loss"]) < LOSS_RTOL
+    m2 = build("MAE_ViT_MsLdCeCd", micro_sd(d), loss="bce")
+    m2._test_draws = draws(d, "cecd_s0")
+    with pytest.raises(csmae_hip.CsmaeError, match="unsupported for un-masked pair losses"):
+        m2(T(d["imgs"]).cuda())
+
+
+def test_four_band_128_fp32():
+    d, base = load("model_micro_c4.npz"), load("model_micro.npz")
+    sd = micro_sd(base)
+    sd.update(micro_sd(d))
+    m = build("MAE_ViT_MsLdCeCd", sd, input_size=128, input_channels=4)
+    m._test_draws = draws(d, "cecd4_s0")
+    loss, pred, mask = m(T(d["imgs"]).cuda())
+    assert rel(loss, d["cecd4_s0_loss"]) < LOSS_RTOL
+    assert np.array_equal(mask.cpu().numpy(), d["cecd4_s0_mask"])
+    loss.backward()
+    names = [str(n) for n in d["cecd4_s0_gradnames"]]
+    params = dict(m.named_parameters())
+    got = np.array([params[n].grad.double().pow(2).sum().item() for n in names])
+    np.testing.assert_allclose(got, d["cecd4_s0_gradsq"], rtol=5e-3, atol=1e-14)
+
+
+def test_micro_bf16_mfma_path_tracks_fp32():
+    d = load("model_micro.npz")
+    sd = micro_sd(d)
+    m = build("MAE_ViT_MsLdCeCd", sd)
+    m.compute_dtype = torch.bfloat16
+    m._test_draws = draws(d, "cecd_s0")
+    loss, pred, mask = m(T(d["imgs"]).cuda())
+    assert rel(loss, d["cecd_s0_loss"]) < 2e-2, (float(loss), float(d["cecd_s0_loss"]))
+    assert np.array_equal(mask.cpu().numpy(), d["cecd_s0_mask"])  # integer path is dtype independent
+    loss.backward()
+    osd, _ = oracle_run(sd, "MsLdCeCd", T(d["imgs"]), draws(d, "cecd_s0"))
+    worst = 1.0
+    for n, p in m.named_parameters():
+        if p.grad is None or n.endswith("attn.qkv.bias"):
+            continue
+        a, b = p.grad.float().cpu().reshape(-1), osd[n].grad.reshape(-1)
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > 0.98, (n, cos)
+    # autocast selects the same path (drop-in for `with torch.cuda.amp.autocast(): model(...)`, engine_pretrain.py:52)
+    m.compute_dtype = None
+    m._test_draws = draws(d, "cecd_s0")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss2, _, _ = m(T(d["imgs"]).cuda())
+    assert float(loss2) == float(loss)
+
+
+def test_vitb_seeded_init_anchors_fp32():
+    """ViT-B/16 at 64^2 built with torch.manual_seed(0) exactly like the reference (BASELINE.json configs[0] geometry)."""
+    import models_mae
+    a = json.load(open(os.path.join(G, "vitb_anchor.json")))
+    d = load("vitb_anchor.npz")
+    torch.manual_seed(0)
+    m = models_mae.mae_vit_base(input_size=64, patch_size="16", loss="mse", device="cuda").cuda().train()
+    m._test_draws = dict(noise=[T(d["cfg1_noise"])], box=None)
+    loss, pred, mask = m(T(d["cfg1_imgs"]).cuda(), mask_ratio=0.75)
+    assert rel(loss, a["cfg1_stats"]["loss"]) < LOSS_RTOL, (float(loss), a["cfg1_stats"]["loss"])
+    assert pred.shape == (2, 16, 768) and mask.shape == (2, 16) and int(mask.sum()) == 24
+    torch.manual_seed(0)
+    m = models_mae.mae_vit_base_MsLdCeCd(input_size=64, patch_size="16", loss="mse", device="cuda").cuda().train()
+    c = a["cecd64"]
+    m._test_draws = dict(noise=[T(d["cecd64_noise0"]), T(d["cecd64_noise1"])], box=tuple(c["box"]))
+    loss, pred, mask = m(T(d["cecd64_imgs"]).cuda())
+    L = m._engines[torch.float32].ws.losses.cpu()
+    assert rel(loss, c["loss"]) < LOSS_RTOL, (float(loss), c["loss"])
+    assert rel(L[1], c["recon"][0]) < LOSS_RTOL and rel(L[2], c["recon"][1]) < LOSS_RTOL and rel(L[4], c["ce"]) < LOSS_RTOL
+    assert abs(float(L[3]) - c["cd"]) < 2e-4 * abs(c["cd"]) + 1e-5
+    assert np.array_equal(mask.cpu().numpy(), d["cecd64_mask"])
+    np.testing.assert_allclose(pred[:, :2, :64].detach().cpu().numpy(), d["cecd64_pred_head"], rtol=2e-3, atol=5e-5)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for n, sq in c["gradsq"].items():
+        got = params[n].grad.double().pow(2).sum().item()
+        assert abs(got - sq) <= 5e-3 * sq + 1e-13, (n, got, sq)
+    assert sorted(n for n, p in params.items() if p.requires_grad and p.grad is None) == sorted(c["nograd"])
+
+
+def test_api_behaviour():
+    import models_mae
+    d = load("model_micro.npz")
+    m = build("MAE_ViT_MsLdCeCd", micro_sd(d))
+    x = T(d["imgs"]).cuda()
+    out = m(x, mask_ratio=0.75, return_embeds=True)
+    assert len(out) == 5 and out[1].shape == (4, 16, 768) and out[2].shape == (4, 16)
+    assert out[3][0].shape == (4, 5, 128) and out[4][1].shape == (4, 17, 64)
+    # mask_seed: same seed -> same masks in both views and across calls (MAE_ViT_Baseline.py:301-302)
+    l1, _, m1 = m(x, mask_seed=7)
+    ws = m._engines[torch.float32].ws
+    assert torch.equal(ws.mask[:4], ws.mask[4:])
+    l2, _, m2 = m(x, mask_seed=7)
+    assert torch.equal(m1, m2)
+    # gradient accumulation: a second backward without zero_grad adds
+    m.zero_grad()
+    m._test_draws = draws(d, "cecd_s0")
+    m(x)[0].backward()
+    g1 = m.decoder_pred.weight.grad.clone()
+    m._test_draws = draws(d, "cecd_s0")
+    (m(x)[0] * 0.5).backward()
+    torch.testing.assert_close(m.decoder_pred.weight.grad, g1 * 1.5, rtol=1e-3, atol=1e-7)
+    # other mask ratios, eval mode, no_grad
+    m.zero_grad()
+    l, p, mk = m(x, mask_ratio=0.5)
+    assert int(mk.sum()) == 4 * 8 and torch.isfinite(l)
+    m.eval()
+    with torch.no_grad():
+        l, p, mk = m(x)
+    assert torch.isfinite(l) and not l.requires_grad
+    # the reference's unusable variant keeps failing loudly; CPU tensors are refused
+    ce = models_mae.MAE_ViT_MsLdCe(**MICRO, input_size=64).cuda()
+    with pytest.raises(RuntimeError, match="running_mean should contain"):
+        ce(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x.cpu())
