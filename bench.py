@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): Cross-Scale MAE pre-training images/s, ViT-B/16 MAE_ViT_MsLdCeCd, 224^2 two-scale crops,
+mask 0.75, bf16 MFMA, batch 128 per GPU, synthetic data, full optimizer steps (crop -> 2-view fwd -> 4 loss terms -> bwd ->
+grad all-reduce -> AdamW).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` prices the whole step against the dense bf16 MFMA peak (118.80 GFLOP per
+image, fwd+bwd) and reports the dominant kernel (the MFMA GEMM family) timed with HIP events on its launch stream.
+`cpu_baseline` times the CPU oracle (oracle/, a validated restatement of the reference step) on the host cores — a reported
+baseline, never the thing being measured."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cross-scale-mae_amd"))
+
+PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md)
+GFLOP_PER_IMAGE = 118.80           # SURVEY.md §8(d), config 2, fwd + bwd (= 3 x 39.599)
+BATCH_PER_GPU, INPUT, PATCH = 128, 224, 16
+
+
+def build(device, batch, world):
+    import models_mae
+    from csmae_hip.optim import FusedAdamW, add_weight_decay
+    from csmae_hip.parallel import DataParallel
+    torch.manual_seed(0)
+    model = models_mae.mae_vit_base_MsLdCeCd(input_size=INPUT, patch_size=str(PATCH), loss="mse", mask_ratio=0.75, device=str(device))
+    model.to(device).train()
+    model.compute_dtype = torch.bfloat16
+    lr = 5e-5 * batch * world / 256  # main_pretrain.py:406-412 (blr 5e-5)
+    opt = FusedAdamW(add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95))
+    wrapped = DataParallel(model) if world > 1 else model
+    return model, wrapped, opt
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle's fwd+bwd+AdamW on the host cores at N=16.  Bounded: one warm-up step, then as many timed
+    steps (<= 3) as fit the budget; if the warm-up alone exceeds the budget it is the sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import csmae_oracle as O
+    import models_mae
+    n = 16
+    threads = min(os.cpu_count() or 1, 64)  # beyond ~64 threads torch's CPU GEMMs at these sizes stop scaling
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = models_mae.mae_vit_base_MsLdCeCd(input_size=INPUT, patch_size=str(PATCH))
+    sd = O.trainable_copy(m.state_dict())
+    cfg = O.make_cfg(input_size=INPUT, patch_size=PATCH, variant="MsLdCeCd", **O.PRESETS["base"])
+    opt = torch.optim.AdamW(O.adamw_groups(sd.items(), 0.05), lr=1e-4, betas=(0.9, 0.95))
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(n, 3, INPUT, INPUT, generator=g)
+    bn = dict(running_mean=sd["predictor.1.running_mean"], running_var=sd["predictor.1.running_var"], num_batches_tracked=sd["predictor.1.num_batches_tracked"])
+
+    def step():
+        box = O.crop_box(INPUT, (0.25, 0.75))
+        O.train_step(sd, cfg, imgs, torch.rand(n, 196, generator=g), torch.rand(n, 196, generator=g), box, opt, bn=bn)
+    t0 = time.time()
+    step()
+    warm = time.time() - t0
+    log(f"cpu_baseline warm-up step {warm:.1f} s on {threads} threads")
+    if warm > seconds_budget:
+        k, dt = 1, warm
+    else:
+        t0, k = time.time(), 0
+        while k < 3 and time.time() - t0 + warm < seconds_budget:
+            step()
+            k += 1
+        k, dt = (k, time.time() - t0) if k else (1, warm)
+    return dict(value=round(n * k / dt, 3), unit="images/s", cores=threads, kind="port",
+                sample=f"oracle/csmae_oracle.py fwd+bwd+AdamW, ViT-B/16 MsLdCeCd 224^2 fp32, N={n}, {k} timed step(s) after warm-up, "
+                       f"{threads} torch threads of {os.cpu_count()} host cores")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (the headline metric is defined at 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    import csmae_hip
+    csmae_hip.load()
+
+    model, wrapped, opt = build(device, a.batch, world)
+    torch.manual_seed(0 + rank)  # main_pretrain.py:368
+    samples = torch.randn(a.batch, 3, INPUT, INPUT, device=device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _, _ = wrapped(samples, mask_ratio=0.75)
+        loss.backward()
+        opt.step()
+        return loss
+
+    log(f"model built; warm-up {a.warmup} steps")
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    log("warm-up done; timing")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    final_loss = float(loss.detach())
+    log(f"timed {a.steps} steps in {elapsed:.3f} s, loss {final_loss:.4f}")
+    if not (final_loss == final_loss and abs(final_loss) < 1e30):
+        raise SystemExit(f"non-finite loss {final_loss}")
+
+    kernel = None
+    if not a.no_kernel_timing:
+        from csmae_hip.ops import KernelTimer
+        with KernelTimer() as kt:
+            step()
+        summ = kt.summary()
+        log("kernel timing pass done")
+        tot_ms = sum(v["ms"] for v in summ.values())
+        tot_fl = sum(v["work"] for v in summ.values())
+        kernel = dict(name="gemm_bf16_kernel (MFMA 16x16x32, all three layouts)", launches_per_step=sum(v["launches"] for v in summ.values()),
+                      ms_per_step=round(tot_ms, 3), tflops=round(tot_fl / tot_ms / 1e9, 1),
+                      by_layout={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=round(v["work"] / v["ms"] / 1e9, 1)) for k, v in summ.items()})
+    if rank == 0:
+        ips = a.batch * world * a.steps / elapsed
+        ach = ips / world * GFLOP_PER_IMAGE / 1e3  # TFLOP/s per GPU
+        scale = a.batch == BATCH_PER_GPU
+        out = {
+            "metric": "pretrain images/sec ViT-B/16 224^2 two-scale", "value": round(ips, 2), "unit": "images/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "MAE_ViT_MsLdCeCd ViT-B/16, 224^2 two-scale crops, mask 0.75, AdamW, full optimizer step",
+                       "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [3, INPUT, INPUT], "parallelism": f"dp{world}",
+                       "headline_config": bool(scale)},
+            "loss": round(final_loss, 5),
+            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                         "traffic": None, "algorithmic_gflop_per_image": GFLOP_PER_IMAGE, "dominant_kernel": kernel},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

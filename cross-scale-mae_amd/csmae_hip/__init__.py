@@ -9,6 +9,8 @@ import ctypes
 import os
 from ctypes import c_float, c_int, c_longlong, c_void_p
 
+import torch  # noqa: F401  -- must come first: libcsmae_hip.so has to bind to the HIP runtime PyTorch already loaded (one runtime per process)
+
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
 LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4}

@@ -389,6 +389,9 @@ class Engine:
         lat_op = ws.lat_lp if self.T == BF16 else ws.enc["x"][c["Ne"]]
         self._dw(ws.dz_lp, lat_op, "decoder_embed")
         ops.gemm(ws.dz_lp, self.W("decoder_embed.weight"), ws.dres_e, trans_b=True, st=st)
+        dp = getattr(self.module, "_dp", None)
+        if dp is not None:
+            dp.grads_ready(self.flat, "tail")  # decoder + heads are final: their all-reduce overlaps the encoder backward
         latent = ws.enc["x"][c["Ne"]]
         if self.has_le:
             ke = c["loss_e"]
@@ -401,12 +404,17 @@ class Engine:
         ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp, B2, Te, st=st)
         for i in reversed(range(c["Ne"])):
             self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, ws.dres_e, ws.dres_e_lp)
+            if dp is not None:
+                dp.grads_ready(self.flat, ("enc", i))
         ops.embed_assemble_bwd(ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
         gw = G("patch_embed.proj.weight").view(D, c["P"])
         tile, kt = (128, 64) if self.T == BF16 else (64, 16)
         ops.gemm(ws.dtok_lp, ws.a_pe[:, : c["P"]], gw, trans_a=True, trans_b=True, epilogue=EPI_ATOMIC,
                  splitk=self._splitk(D, c["P"], ws.dtok_lp.shape[0], tile, kt), st=st)
         ops.colsum(ws.dtok_lp, G("patch_embed.proj.bias"), st=st)
+        if dp is not None:
+            dp.grads_ready(self.flat, "stem")
+            dp.backward_done(self.flat)
         # hand the gradient views to autograd's .grad slots (frozen and unused parameters keep None — encoder_norm: E1)
         for name, p in self.flat.params.items():
             if p.requires_grad and not name.startswith("encoder_norm."):

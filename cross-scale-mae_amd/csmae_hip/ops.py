@@ -8,6 +8,42 @@ import torch
 from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, LOSS_KINDS, check, load
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
+_timer = None
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are enqueued on (bench.py roofline leg)."""
+
+    def __init__(self):
+        self.records, self._e0 = [], None
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *a):
+        global _timer
+        _timer = None
+
+    def begin(self):
+        self._e0 = torch.cuda.Event(enable_timing=True)
+        self._e0.record()
+
+    def end(self, kind, work):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((kind, work, self._e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, work, e0, e1 in self.records:
+            d = out.setdefault(kind, dict(ms=0.0, work=0.0, launches=0))
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+            d["launches"] += 1
+        return out
 
 
 def dt(t: torch.Tensor) -> int:
@@ -32,9 +68,13 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NON
     Kb, N = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
     assert K == Kb and out.shape[0] == M and out.shape[1] == N, (a.shape, b.shape, out.shape, trans_a, trans_b)
     assert a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    if _timer is not None:
+        _timer.begin()
     check(load().csmae_gemm(dt(a), int(trans_a), int(trans_b), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0),
                             dt(out), _p(bias), epilogue, _p(aux), aux.stride(0) if aux is not None else 0, _p(resid),
                             resid.stride(0) if resid is not None else 0, splitk, st if st is not None else stream()), "csmae_gemm")
+    if _timer is not None:
+        _timer.end(("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32") + ("_T" if trans_a else "_N") + ("N" if trans_b else "T"), 2.0 * M * N * K)
     return out
 
 

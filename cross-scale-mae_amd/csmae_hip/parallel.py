@@ -1,0 +1,157 @@
+"""Batch-sharded data parallelism for one 8-GPU MI355X node: one process per GPU, RCCL over xGMI.
+
+Replaces `torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)` of the reference
+(main_pretrain.py:417-421).  The path has exactly one bulk exchange per step: the gradient mean.  Because all
+gradients live in one flat fp32 buffer in parameter-registration order, the exchange is a handful of large contiguous
+all-reduces issued on a side stream while the encoder's backward GEMMs are still running (decoder + heads are ready first and
+are 24 % of the bytes).  xGMI is point-to-point (7 links x ~153 GB/s), so few large messages beat DDP's 25 MB buckets.
+
+`GradSync` is device-agnostic (works on CPU tensors with gloo) so the N>1 logic is covered by world-size-2 tests without a GPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+class GradSync:
+    """Mean-all-reduce of contiguous ranges of a flat gradient buffer, optionally on a side stream."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, comm_dtype: Optional[torch.dtype] = None):
+        self.g = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if is_dist() else 1
+        self.comm_dtype = comm_dtype
+        self.cuda = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream() if self.cuda else None
+        self._staging = torch.empty(flat_grad.numel(), dtype=comm_dtype, device=flat_grad.device) if comm_dtype not in (None, flat_grad.dtype) else None
+        self._pending = False
+        # gloo has no AVG; RCCL does
+        self._avg = self.cuda
+
+    def reduce_range(self, lo: int, hi: int):
+        """Enqueue mean-all-reduce of g[lo:hi].  On GPU it runs on the side stream after everything already enqueued on the
+        current stream (the kernels that produced g[lo:hi])."""
+        if self.world == 1 or hi <= lo:
+            return
+        seg = self.g[lo:hi]
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._reduce(seg, lo, hi)
+            self._pending = True
+        else:
+            self._reduce(seg, lo, hi)
+
+    def _reduce(self, seg, lo, hi):
+        if self._staging is not None:  # bf16 payload: halves xGMI bytes (SURVEY.md §8e budget)
+            st = self._staging[lo:hi]
+            st.copy_(seg)
+            dist.all_reduce(st, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group)
+            seg.copy_(st)
+            if not self._avg:
+                seg.div_(self.world)
+        elif self._avg:
+            dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+            seg.div_(self.world)
+
+    def finish(self):
+        """Make the reduced gradients visible to the current stream (the optimizer's stream)."""
+        if self._pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self._pending = False
+
+    def broadcast(self, tensors: List[torch.Tensor], src: int = 0):
+        if self.world == 1:
+            return
+        for t in tensors:
+            dist.broadcast(t, src=src, group=self.group)
+
+
+def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket: int = 4) -> List[Tuple[str, int, int]]:
+    """Contiguous flat ranges in gradient-READY order (reverse registration order): tail (decoder + heads), encoder layers in
+    groups from the last to the first, then the stem (tokens, patch embed, decoder_embed)."""
+    def start(prefix):
+        for n in names:
+            if n.startswith(prefix):
+                return slots[n][0]
+        return None
+    total = max(o + ((n + 7) // 8) * 8 for o, n, _ in slots.values())
+    out = []
+    dec0 = start("decoder.0.")
+    enc0 = start("encoder.0.")
+    out.append(("tail", dec0, total))
+    hi = dec0
+    i = n_encoder
+    while i > 0:
+        j = max(0, i - enc_per_bucket)
+        lo = start(f"encoder.{j}.")
+        out.append((("enc", j), lo, hi))  # final once encoder layer j's backward has been enqueued
+        hi, i = lo, j
+    out.append(("stem", 0, enc0))
+    return out
+
+
+class DataParallel(torch.nn.Module):
+    """Wrapper with DDP's surface (`.module`, forward passthrough, `no_sync()`): hooks the engine's backward so gradient
+    ranges are all-reduced as soon as they are final."""
+
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, comm_dtype: Optional[torch.dtype] = None, **_):
+        super().__init__()
+        self.module = module
+        self.comm_dtype = comm_dtype
+        self.require_backward_grad_sync = True
+        self._sync: Optional[GradSync] = None
+        module.__dict__["_dp"] = self  # plain attribute (not a registered submodule: that would make the module tree cyclic)
+
+    def _ensure(self, flat):
+        if self._sync is None or self._sync.g is not flat.g:
+            self._sync = GradSync(flat.g, comm_dtype=self.comm_dtype)
+            # rank-0 parameters and buffers win (DDP constructor semantics, main_pretrain.py:418-420)
+            self._sync.broadcast([flat.p] + [b for b in self.module.buffers()])
+            n_enc = len(self.module.encoder)
+            self._ranges = {name: (lo, hi) for name, lo, hi in bucket_ranges(flat.slots, flat.names, n_enc)}
+        return self._sync
+
+    # called by Engine.backward
+    def grads_ready(self, flat, name):
+        if not self.require_backward_grad_sync or not is_dist():
+            return
+        sync = self._ensure(flat)
+        if name in self._ranges:
+            sync.reduce_range(*self._ranges[name])
+
+    def backward_done(self, flat):
+        if self._sync is not None:
+            self._sync.finish()
+
+    def forward(self, *args, **kwargs):
+        if is_dist():
+            if self.module._flat is None or not self.module._flat.still_homed():
+                self.module._engine(args[0])  # homes the parameters in the flat buffers so they can be broadcast before first use
+            self._ensure(self.module._flat)
+            if self.module.training:  # DDP broadcast_buffers=True: BatchNorm statistics follow rank 0
+                self._sync.broadcast(list(self.module.buffers()))
+        return self.module(*args, **kwargs)
+
+    class _NoSync:
+        def __init__(self, dp):
+            self.dp = dp
+
+        def __enter__(self):
+            self.old = self.dp.require_backward_grad_sync
+            self.dp.require_backward_grad_sync = False
+
+        def __exit__(self, *a):
+            self.dp.require_backward_grad_sync = self.old
+
+    def no_sync(self):
+        return DataParallel._NoSync(self)
