@@ -1,0 +1,160 @@
+"""CPU-only checks of the host-side mirror of the reference interface: CLI surface, factories / state_dict manifest / seeded
+init (vs the reference's own values in tests/golden/manifest.json), LR schedule, the epoch loop (with a stub model), meters,
+the scaler contract, checkpoint layout."""
+import json
+import math
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def checksum(t):
+    flat = t.double().reshape(-1)
+    w = torch.arange(flat.numel(), dtype=torch.float64) % 97 + 1
+    return [float(flat.sum()), float(flat.abs().sum()), float((flat * w).sum()), [float(x) for x in flat[:4]]]
+
+
+def test_cli_matches_reference_flags():
+    import main_pretrain
+    a = main_pretrain.get_args_parser().parse_args([])
+    expect = dict(batch_size=512, epochs=200, accum_iter=1, model="mae_vit_base", input_size=224, patch_size=16, print_level=1, mask_ratio=0.75,
+                  attn_name="scaled_dot_product", use_xformers=False, ffn_name="MLP", spatial_mask=False, loss="mse", norm_pix_loss=False,
+                  weight_decay=0.05, lr=None, blr=5e-5, min_lr=0.0, warmup_epochs=40, train_path="./train.csv", dataset_type="fmow_rgb",
+                  masked_bands=None, dropped_bands=None, output_dir=None, output_dir_base="./out", val_img_path="./images/", device="cuda",
+                  seed=0, resume=None, start_epoch=0, wandb_entity="utk-iccv23", wandb_project=None, wandb_id=None, num_workers=os.cpu_count(),
+                  pin_mem=True, world_size=1, dist_on_itp=False, dist_url="env://")
+    for k, v in expect.items():
+        assert getattr(a, k) == v, k
+    assert int(a.local_rank) == int(os.getenv("LOCAL_RANK", 0))
+    b = main_pretrain.get_args_parser().parse_args(["--patch_size", "14", "--no_pin_mem", "--resume", "", "--masked_bands", "1", "2", "--loss", "ssim"])
+    assert b.patch_size == "14" and b.pin_mem is False and b.resume is None and b.masked_bands == [1, 2]
+    with pytest.raises(SystemExit):
+        main_pretrain.get_args_parser().parse_args(["-h"])  # add_help=False in the reference
+
+
+def test_factories_manifest_and_seeded_init_match_reference():
+    import models_mae
+    man = json.load(open(os.path.join(G, "manifest.json")))
+    for f, m in man.items():
+        size = 224 if "@224" in f else 64
+        torch.manual_seed(0)
+        mod = getattr(models_mae, f.split("@")[0])(input_size=size, patch_size="16", loss="mse", device="cpu")
+        sd = mod.state_dict()
+        assert list(sd.keys()) == m["keys"], f
+        assert [list(v.shape) for v in sd.values()] == m["shapes"], f
+        assert sum(p.numel() for p in mod.parameters() if p.requires_grad) == m["trainable"], f
+        if "param_order" in m:
+            assert [n for n, _ in mod.named_parameters()] == m["param_order"]
+            assert [bool(p.requires_grad) for _, p in mod.named_parameters()] == m["requires_grad"]
+        for k, c in m.get("checksums", {}).items():
+            assert checksum(sd[k]) == c, (f, k)  # bit-identical seeded initialisation
+
+
+def test_constructor_surface():
+    import models_mae
+    a = vars(__import__("main_pretrain").get_args_parser().parse_args(["--input_size", "64"]))
+    a.pop("input_channels")
+    m = models_mae.__dict__["mae_vit_base_MsLdCeCd"](**a)  # the whole namespace is splatted in (main_pretrain.py:398)
+    assert (m.input_size, m.input_channels, m.patch_size, m.dim_model, m.decoder_embed_dim, m.num_patches) == (64, 3, 16, 768, 512, 16)
+    assert m.patch_embed.patch_size == (16, 16) and m.patch_embed.num_patches == 16 and m.loss == "mse" and m.norm_pix_loss is False
+    assert m.no_weight_decay() == {} and m.use_xformers is False and m.mask_ratio == 0.75
+    x = torch.randn(2, 3, 64, 64)
+    assert torch.equal(m.unpatchify(m.patchify(x, 16, 3), 16, 3), x)
+    with pytest.raises(NotImplementedError, match="SSIM"):
+        models_mae.mae_vit_base(input_size=64, loss="ssim")
+    with pytest.raises(NotImplementedError, match="xFormers"):
+        models_mae.mae_vit_base(input_size=64, use_xformers=True)
+    with pytest.raises(AssertionError):
+        models_mae.mae_vit_base(input_size=64, attn_name="linformer")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x)  # the product path never computes on the CPU
+
+
+def test_lr_schedule_matches_reference_table():
+    import util.lr_sched as lr_sched
+    a = json.load(open(os.path.join(G, "vitb_anchor.json")))
+    for lr, min_lr, wu, ep, e, want, g0, g1 in a["lr_table"]:
+        opt = types.SimpleNamespace(param_groups=[dict(lr=0.0), dict(lr=0.0, lr_scale=0.5)])
+        got = lr_sched.adjust_learning_rate(opt, e, types.SimpleNamespace(lr=lr, min_lr=min_lr, warmup_epochs=wu, epochs=ep))
+        assert got == pytest.approx(want, rel=1e-12, abs=1e-18)
+        assert opt.param_groups[0]["lr"] == pytest.approx(g0, rel=1e-12, abs=1e-18) and opt.param_groups[1]["lr"] == pytest.approx(g1, rel=1e-12, abs=1e-18)
+
+
+class _Stub(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([1.0, -2.0]))
+        self.calls = []
+
+    def forward(self, samples, mask_ratio=0.75):
+        self.calls.append(mask_ratio)
+        return (self.w * samples.mean()).pow(2).sum(), None, None
+
+
+def test_train_one_epoch_contract_on_cpu():
+    from engine_pretrain import train_one_epoch
+    from util.misc import NativeScalerWithGradNormCount
+    m = _Stub()
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    args = types.SimpleNamespace(accum_iter=2, lr=1e-2, min_lr=0.0, warmup_epochs=1, epochs=4, mask_ratio=0.6)
+    data = [(torch.full((2, 1), float(i + 1)), None) for i in range(6)]
+    stats = train_one_epoch(m, data, opt, torch.device("cpu"), 1, NativeScalerWithGradNormCount(), log_writer=None, args=args)
+    assert set(stats) == {"lr", "loss", "time_epoch", "time_step"}
+    assert m.calls == [0.6] * 6
+    # lr of the last update step: iteration 4 of 6 in epoch 1 -> fractional epoch 1 + 4/6 (per-iteration schedule, accum aware)
+    e = 1 + 4 / 6
+    want = 0.5 * 1e-2 * (1 + math.cos(math.pi * (e - 1) / 3))
+    assert opt.param_groups[0]["lr"] == pytest.approx(want)
+    w0 = torch.tensor([1.0, -2.0])
+    assert stats["loss"] > 0 and not torch.equal(m.w.detach(), w0)
+    bad = [(torch.full((2, 1), float("nan")), None)]
+    with pytest.raises(ValueError, match="stopping training"):
+        train_one_epoch(_Stub(), bad, opt, torch.device("cpu"), 0, NativeScalerWithGradNormCount(), args=args)
+
+
+def test_meters_scaler_and_checkpoint_layout(tmp_path):
+    import util.misc as misc
+    sv = misc.SmoothedValue(window_size=3)
+    for v in (1.0, 2.0, 3.0, 10.0):
+        sv.update(v)
+    assert sv.median == 3.0 and sv.global_avg == 4.0 and sv.max == 10.0 and sv.value == 10.0 and sv.avg == pytest.approx(5.0)
+    sc = misc.NativeScalerWithGradNormCount()
+    assert sc.state_dict_key == "amp_scaler" and sc.state_dict() == {}
+    m = _Stub()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    loss = m(torch.ones(2, 1))[0]
+    assert sc(loss, opt, parameters=m.parameters(), update_grad=False) is None and m.w.grad is not None
+    norm = sc(m(torch.ones(2, 1))[0], opt, clip_grad=1.0, parameters=m.parameters())
+    assert float(norm) > 0
+    args = types.SimpleNamespace(output_dir=str(tmp_path), resume=None)
+    misc.save_model(args, 3, m, m, opt, sc)
+    ck = torch.load(tmp_path / "checkpoint-3.pth", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch", "scaler", "args"} and ck["epoch"] == 3
+    args.resume = str(tmp_path / "checkpoint-3.pth")
+    m2 = _Stub()
+    misc.load_model(args, m2, torch.optim.SGD(m2.parameters(), lr=0.1), sc)
+    assert torch.equal(m2.w, m.w) and args.start_epoch == 4
+    assert misc.all_reduce_mean(1.5) == 1.5 and misc.get_world_size() == 1 and misc.is_main_process()
+
+
+def test_sincos_table_is_the_reference_table():
+    from util.pos_embed import get_2d_sincos_pos_embed
+    d = np.load(os.path.join(G, "sincos.npz"))
+    for dim, grid in [(128, 4), (64, 4), (768, 4), (512, 4)]:
+        assert np.array_equal(get_2d_sincos_pos_embed(dim, grid, cls_token=True), d[f"full_{dim}_{grid}"])
+    for dim, grid in [(768, 14), (512, 14), (1024, 16), (1280, 16)]:
+        assert np.array_equal(get_2d_sincos_pos_embed(dim, grid, cls_token=True).reshape(-1)[d[f"idx_{dim}_{grid}"]], d[f"val_{dim}_{grid}"])
+
+
+def test_crop_box_sampler_consumes_the_cpu_rng_like_the_reference():
+    from models_mae.MAE_ViT_MsLd import sample_crop_box
+    d = np.load(os.path.join(G, "crop.npz"))
+    torch.manual_seed(0)
+    assert [list(sample_crop_box(224, (0.25, 0.75))) for _ in range(16)] == d["rrc_seed0_224"].tolist()
+    torch.manual_seed(123)
+    assert [list(sample_crop_box(64, (0.25, 0.75))) for _ in range(16)] == d["rrc_seed123_64"].tolist()
