@@ -172,6 +172,7 @@ class Workspace:
         self.demb = E(Md, Dd, **f32)
         self.dz_lp = E(Me, Dd, **lp)
         self.dtok_lp = E(B2 * max(keep, 1), D, **lp)
+        self.dw_ws = E(64 * 1024 * 1024, **f32)  # split-K slabs of the weight-gradient GEMMs (256 MiB)
 
 
 class Engine:
@@ -239,7 +240,7 @@ class Engine:
         tile, kt = (128, 64) if self.T == BF16 else (64, 16)
         sk = self._splitk(gw2.shape[0], gw2.shape[1], dy.shape[0], tile, kt)
         dyv, xv = dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]]
-        ops.gemm(dyv, xv, gw2, trans_a=True, trans_b=True, epilogue=EPI_ATOMIC, splitk=sk, st=self.st)
+        ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, st=self.st)
         ops.colsum(dyv, self.flat.G(name + ".bias"), st=self.st)
 
     # ------------------------------------------------------------------ transformer block
@@ -407,10 +408,7 @@ class Engine:
             if dp is not None:
                 dp.grads_ready(self.flat, ("enc", i))
         ops.embed_assemble_bwd(ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
-        gw = G("patch_embed.proj.weight").view(D, c["P"])
-        tile, kt = (128, 64) if self.T == BF16 else (64, 16)
-        ops.gemm(ws.dtok_lp, ws.a_pe[:, : c["P"]], gw, trans_a=True, trans_b=True, epilogue=EPI_ATOMIC,
-                 splitk=self._splitk(D, c["P"], ws.dtok_lp.shape[0], tile, kt), st=st)
+        ops.gemm_dw(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), ws.dw_ws, st=st)
         ops.colsum(ws.dtok_lp, G("patch_embed.proj.bias"), st=st)
         if dp is not None:
             dp.grads_ready(self.flat, "stem")

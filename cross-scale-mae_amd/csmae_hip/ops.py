@@ -78,6 +78,19 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NON
     return out
 
 
+def gemm_dw(dy, x, dw, workspace, st=None):
+    """dw[out,in] (fp32, contiguous) += dy[tokens,out]^T x[tokens,in] via split-K slabs in `workspace` (fp32)."""
+    K, M = dy.shape
+    N = x.shape[1]
+    assert x.shape[0] == K and dw.shape == (M, N) and dw.is_contiguous() and dy.dtype == x.dtype
+    if _timer is not None:
+        _timer.begin()
+    check(load().csmae_gemm_dw(dt(dy), M, N, K, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(workspace), workspace.numel(),
+                               st if st is not None else stream()), "csmae_gemm_dw")
+    if _timer is not None:
+        _timer.end(("gemm_bf16" if dy.dtype == torch.bfloat16 else "gemm_f32") + "_TN", 2.0 * M * N * K)
+
+
 def attn_fwd(qkv, out, lse, B, T, H, hd, st=None):
     check(load().csmae_attn_fwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(lse), st if st is not None else stream()), "csmae_attn_fwd")
 

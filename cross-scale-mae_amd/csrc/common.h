@@ -98,4 +98,25 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7): one exp + one rcp instead of libm's ulp-exact erff.  Used by the bf16
+// epilogues, where the result is rounded to 8 mantissa bits anyway; the fp32 parity path keeps erff.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float r = 1.0f - poly * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd(float x);
+template <> __device__ __forceinline__ float gelu_fwd<float>(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_fwd<bf16_t>(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+template <typename T> __device__ __forceinline__ float gelu_bwd(float x);
+template <> __device__ __forceinline__ float gelu_bwd<float>(float x) { return gelu_erf_grad(x); }
+template <> __device__ __forceinline__ float gelu_bwd<bf16_t>(float x) {
+  return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

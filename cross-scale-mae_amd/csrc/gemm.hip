@@ -22,7 +22,8 @@
 #define EPI_GELU 1    // aux = acc + bias ; C = gelu(aux)
 #define EPI_RESID 2   // C = acc + bias + resid (resid fp32)
 #define EPI_DGELU 3   // C = acc * gelu'(aux)
-#define EPI_ATOMIC 4  // C(fp32) += acc   (split-K weight gradients)
+#define EPI_ATOMIC 4  // C(fp32) += acc   (split-K, atomics)
+#define EPI_SPLIT 5   // C(fp32)[split] = acc  (split-K partial slabs, reduced by dw_reduce_kernel: deterministic, no atomics)
 
 struct GemmArgs {
   const void* A; const void* B; void* C; const float* bias; void* aux; const float* resid;
@@ -30,6 +31,8 @@ struct GemmArgs {
   int M, N, K;
   int c_dtype, epi, splitk, tiles_m, tiles_n, ktiles, ktiles_per_split;
   unsigned a_bytes, b_bytes;
+  int force_cfg;
+  long long split_stride;
 };
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -41,13 +44,13 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& p, int m, int n, f4_t
     // the saved pre-activation is what backward sees: evaluate gelu on the value as stored (rounded for bf16)
     v = round4<TC>(v);
     st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)m * p.ldaux + n, v);
-    v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+    v[0] = gelu_fwd<TC>(v[0]); v[1] = gelu_fwd<TC>(v[1]); v[2] = gelu_fwd<TC>(v[2]); v[3] = gelu_fwd<TC>(v[3]);
   } else if (p.epi == EPI_RESID) {
     f4_t r = *reinterpret_cast<const f4_t*>(p.resid + (long long)m * p.ldr + n);
     v += r;
   } else if (p.epi == EPI_DGELU) {
     f4_t q = ld4<TC>(reinterpret_cast<const TC*>(p.aux) + (long long)m * p.ldaux + n);
-    v[0] *= gelu_erf_grad(q[0]); v[1] *= gelu_erf_grad(q[1]); v[2] *= gelu_erf_grad(q[2]); v[3] *= gelu_erf_grad(q[3]);
+    v[0] *= gelu_bwd<TC>(q[0]); v[1] *= gelu_bwd<TC>(q[1]); v[2] *= gelu_bwd<TC>(q[2]); v[3] *= gelu_bwd<TC>(q[3]);
   }
   st4<TC>(c, v);
 }
@@ -71,141 +74,226 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 }
 
 // ------------------------------------------------------------------------------------ bf16 MFMA
+// Block tile BM x BN x 32, NW = (BM/WM)*(BN/WN) waves, each wave WM x WN (16x16x32 MFMA fragments).  Measured on MI355X the
+// first (128x128x64, 2-stage) version of this kernel was bound by the HBM/L2 -> LDS path at ~6 TB/s (64 flop per staged byte,
+// one K-tile of prefetch): so tiles are as large as the problem allows (256x256: 128 flop/B) and the LDS ring is 4 stages deep
+// with counted `s_waitcnt vmcnt(N)` + raw s_barrier, keeping three K-tiles of `buffer_load ... lds` in flight across barriers.
 #define OOB_OFF 0xFFFFFFF0u
+#define GEMM_BK 32
 __device__ __forceinline__ int tr_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[65536];  // [2 buffers][A 16 KiB | B 16 KiB]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+template <bool TR, int W>   // staging descriptor of one 1-KiB DMA piece of an operand image
+struct PieceDesc {
+  unsigned off; int kidx; bool ok;
+  __device__ __forceinline__ void init(int piece, int lane, long long base0, long long extent, long long ld) {
+    if (!TR) {  // image [W rows][32 k] : 64-B rows, 16-B chunk swizzle c ^ ((row >> 1) & 3)
+      int row = piece * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 1) & 3);
+      long long gr = base0 + row;
+      ok = gr < extent; kidx = c * 8;
+      off = (unsigned)((gr * ld + c * 8) * 2);
+    } else {    // image [32 rows k][W cols] : 2W-B rows, 32-B granule swizzle q ^ tr_key(row)
+      constexpr int LPR = W / 8, RPP = 64 / LPR;
+      int row = piece * RPP + lane / LPR, s16 = lane % LPR;
+      int ch = ((((s16 >> 1) ^ tr_key(row)) << 1) | (s16 & 1));
+      ok = true; kidx = row;
+      off = (unsigned)(((long long)row * ld + base0 + ch * 8) * 2);
+    }
+  }
+};
+
+// Row-segment epilogue.  vmcnt is one in-order counter for loads AND stores on gfx9/CDNA: a residual / aux load issued after a
+// store cannot be consumed before that store has been acknowledged by memory (~2 us under load).  The first version of this
+// epilogue interleaved "load, add, store" per fragment and spent 45 % of the GEMM time in those waits.  So every global load of
+// a phase is issued before the phase's first store, and the stores then go out back to back.
+template <typename TC, int EPI, int FM, int FN, int WM, int EROWS, int ESTR, int LPR, int RPP>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
+  constexpr int NPASS = EROWS / RPP, NPART = WM / EROWS;
+  constexpr bool NEEDS_LOAD = EPI == EPI_RESID || EPI == EPI_DGELU;
+  constexpr bool PRELOAD_ALL = (WM <= 64);  // all residual/aux rows of the wave tile fit in registers
+  const int col = (lane % LPR) * 4, rsub = lane / LPR;
+  const int gn = nbase + col;
+  const bool colok = gn < p.N;
+  const int gnc = colok ? gn : 0;           // clamped addresses: loads are unconditional (no divergent control flow), stores are predicated
+  f4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f4_t*>(p.bias + gnc);
+  f4_t ld[NEEDS_LOAD ? (PRELOAD_ALL ? NPART * NPASS : NPASS) : 1];
+  auto load_part = [&](int part, int slot0) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
+      if (EPI == EPI_RESID) ld[slot0 + ps] = *reinterpret_cast<const f4_t*>(p.resid + (long long)gm * p.ldr + gnc);
+      else ld[slot0 + ps] = ld4<TC>(reinterpret_cast<const TC*>(p.aux) + (long long)gm * p.ldaux + gnc);
+    }
+  };
+  if (PRELOAD_ALL && NEEDS_LOAD) {
+#pragma unroll
+    for (int part = 0; part < NPART; ++part) load_part(part, part * NPASS);
+  }
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) {
+    if (!PRELOAD_ALL && NEEDS_LOAD) load_part(part, 0);
+#pragma unroll
+    for (int ii = 0; ii < EROWS / 16; ++ii)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = acc[part * (EROWS / 16) + ii][j];
+    // every load of this phase has been issued: retire them once, here, so that no wait is needed between the stores below
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int gm = mbase + part * EROWS + ps * RPP + rsub;
+      f4_t v = *reinterpret_cast<const f4_t*>(ew + (ps * RPP + rsub) * ESTR + col) + bias4;
+      if (EPI == EPI_GELU) v = round4<TC>(v);  // backward sees the stored (rounded) pre-activation: evaluate gelu on exactly that value
+      f4_t o = v;
+      if (EPI == EPI_GELU) { o[0] = gelu_fwd<TC>(v[0]); o[1] = gelu_fwd<TC>(v[1]); o[2] = gelu_fwd<TC>(v[2]); o[3] = gelu_fwd<TC>(v[3]); }
+      if (EPI == EPI_RESID) o = v + ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
+      if (EPI == EPI_DGELU) {
+        const f4_t x = ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
+        o[0] = v[0] * gelu_bwd<TC>(x[0]); o[1] = v[1] * gelu_bwd<TC>(x[1]); o[2] = v[2] * gelu_bwd<TC>(x[2]); o[3] = v[3] * gelu_bwd<TC>(x[3]);
+      }
+      if (colok && gm < p.M) {
+        if (EPI == EPI_GELU) st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)gm * p.ldaux + gn, v);
+        st4<TC>(reinterpret_cast<TC*>(p.C) + (long long)gm * p.ldc + gn, o);
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB, int BM, int BN, int WM, int WN, int GEMM_STAGES>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(GemmArgs p) {
+  constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, FM = WM / 16, FN = WN / 16;
+  constexpr int A_BYTES = BM * GEMM_BK * 2, B_BYTES = BN * GEMM_BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024, PPW = (PA + PB) / NW;
+  static_assert((PA + PB) % NW == 0, "DMA pieces must divide evenly over the waves");
+  __shared__ __attribute__((aligned(16))) char smem[GEMM_STAGES * STAGE];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = lane & 15, g = lane >> 4;
   const int tiles = p.tiles_m * p.tiles_n;
   const int wg = xcd_remap(blockIdx.x, tiles * p.splitk);
   const int split = wg / tiles, tile = wg - split * tiles;
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  const int m0 = tm * 128, n0 = tn * 128;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int kt_begin = split * p.ktiles_per_split;
   const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles);
+  if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
+  if (p.epi == EPI_SPLIT) p.C = reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride;
 
   auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
   auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  const unsigned kstepA = TA ? (unsigned)(GEMM_BK * p.lda * 2) : (unsigned)(GEMM_BK * 2);
+  const unsigned kstepB = TB ? (unsigned)(GEMM_BK * p.ldb * 2) : (unsigned)(GEMM_BK * 2);
 
-  // per-lane staging descriptors: 4 DMA pieces (1 KiB each) per operand per wave
-  unsigned offA[4], offB[4];   // byte offset at kt = 0 (without the k advance)
-  int kA[4], kB[4];            // k index (within tile) whose validity must be checked against K
-  bool rowokA[4], rowokB[4];
+  unsigned poff[PPW]; int pk[PPW]; bool pok[PPW];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int piece = w * 4 + q;
-    if (!TA) {  // tile image [128 rows m][64 k], 128-B rows, 16-B chunk swizzle c ^ (row & 7)
-      int row = piece * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
-      long long gr = (long long)m0 + row;
-      rowokA[q] = gr < p.M; kA[q] = c * 8;
-      offA[q] = (unsigned)((gr * p.lda + c * 8) * 2);
-    } else {    // tile image [64 rows k][128 m], 256-B rows, 32-B granule swizzle
-      int row = piece * 4 + (lane >> 4), s16 = lane & 15;
-      int ch = ((((s16 >> 1) ^ tr_key(row)) << 1) | (s16 & 1));
-      rowokA[q] = true; kA[q] = row;
-      offA[q] = (unsigned)(((long long)row * p.lda + m0 + ch * 8) * 2);
-    }
-    if (!TB) {
-      int row = piece * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
-      long long gr = (long long)n0 + row;
-      rowokB[q] = gr < p.N; kB[q] = c * 8;
-      offB[q] = (unsigned)((gr * p.ldb + c * 8) * 2);
-    } else {
-      int row = piece * 4 + (lane >> 4), s16 = lane & 15;
-      int ch = ((((s16 >> 1) ^ tr_key(row)) << 1) | (s16 & 1));
-      rowokB[q] = true; kB[q] = row;
-      offB[q] = (unsigned)(((long long)row * p.ldb + n0 + ch * 8) * 2);
-    }
+  for (int q = 0; q < PPW; ++q) {
+    const int pi = w * PPW + q;
+    if (pi < PA) { PieceDesc<TA, BM> d; d.init(pi, lane, m0, p.M, p.lda); poff[q] = d.off; pk[q] = d.kidx; pok[q] = d.ok; }
+    else { PieceDesc<TB, BN> d; d.init(pi - PA, lane, n0, p.N, p.ldb); poff[q] = d.off; pk[q] = d.kidx; pok[q] = d.ok; }
   }
-  const unsigned kstepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
-  const unsigned kstepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
-
-  auto stage = [&](int buf, int kt) {
-    char* sa = smem + buf * 32768;
-    char* sb = sa + 16384;
-    const int k0 = kt * 64;
+  auto stage = [&](int kt) {
+    char* base = smem + ((kt - kt_begin) % GEMM_STAGES) * STAGE;
+    const int k0 = kt * GEMM_BK;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned oa = (rowokA[q] && (k0 + kA[q] < p.K)) ? offA[q] + (unsigned)kt * kstepA : OOB_OFF;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, sa + (w * 4 + q) * 1024), 16, (int)oa, 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned ob = (rowokB[q] && (k0 + kB[q] < p.K)) ? offB[q] + (unsigned)kt * kstepB : OOB_OFF;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, sb + (w * 4 + q) * 1024), 16, (int)ob, 0, 0, 0);
+    for (int q = 0; q < PPW; ++q) {
+      const int pi = w * PPW + q;
+      const bool ok = pok[q] && (k0 + pk[q] < p.K);
+      if (pi < PA) {
+        unsigned o = ok ? poff[q] + (unsigned)kt * kstepA : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, base + pi * 1024), 16, (int)o, 0, 0, 0);
+      } else {
+        unsigned o = ok ? poff[q] + (unsigned)kt * kstepB : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, base + A_BYTES + (pi - PA) * 1024), 16, (int)o, 0, 0, 0);
+      }
     }
   };
 
-  f4_t acc[4][4];
+  f4_t acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const int wm = (w / NWN) * WM, wn = (w % NWN) * WN;
 
-  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
-  // fragment read offsets (bytes, within an operand image), k-slice 0; slice 1 adds a constant
-  int rdA[4], rdB[4];
+  // per-lane fragment offsets inside an operand image
+  int ra[FM], rb[FN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (!TA) { int row = wm + i * 16 + t; rdA[i] = row * 128; }
-    else     { rdA[i] = (wm >> 4) + i; }
-    if (!TB) { int row = wn + i * 16 + t; rdB[i] = row * 128; }
-    else     { rdB[i] = (wn >> 4) + i; }
+  for (int i = 0; i < FM; ++i) {
+    if (!TA) { int row = wm + i * 16 + t; ra[i] = row * 64 + ((g ^ ((row >> 1) & 3)) << 4); }
+    else { int q = (wm >> 4) + i, key = (t >> 2) | ((g & 1) << 2); ra[i] = ((q ^ key) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BM * 2); }
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    if (!TB) { int row = wn + j * 16 + t; rb[j] = row * 64 + ((g ^ ((row >> 1) & 3)) << 4); }
+    else { int q = (wn >> 4) + j, key = (t >> 2) | ((g & 1) << 2); rb[j] = ((q ^ key) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BN * 2); }
   }
 
-  if (kt_begin < kt_end) stage(0, kt_begin);
+#pragma unroll
+  for (int s = 0; s < GEMM_STAGES - 1; ++s)
+    if (kt_begin + s < kt_end) stage(kt_begin + s);
+
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
-    const char* sa = smem + buf * 32768;
-    const char* sb = sa + 16384;
+    // wait for this wave's pieces of tile kt (tiles kt+1, kt+2 may stay in flight), then meet the other waves
+    if (GEMM_STAGES >= 4 && kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (GEMM_STAGES >= 3 && kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + GEMM_STAGES - 1 < kt_end && !(p.force_cfg & 64)) stage(kt + GEMM_STAGES - 1);  // refills the stage every wave finished reading before the barrier
+    if (p.force_cfg & 32) continue;
+    const char* sa = smem + ((kt - kt_begin) % GEMM_STAGES) * STAGE;
+    const char* sb = sa + A_BYTES;
+    s8_t fa[FM], fb[FN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      s8_t fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (!TA) {
-          int row7 = (wm + i * 16 + t) & 7;
-          fa[i] = *reinterpret_cast<const s8_t*>(sa + rdA[i] + (((ks * 4 + g) ^ row7) << 4));
-        } else {
-          int kr = ks * 32 + 8 * g + (t >> 2);
-          int key = (t >> 2) | ((g & 1) << 2);
-          const char* base = sa + ((rdA[i] ^ key) << 5) + (t & 3) * 8;
-          s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, base + kr * 256));
-          s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, base + (kr + 4) * 256));
-          fa[i] = s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-        if (!TB) {
-          int row7 = (wn + i * 16 + t) & 7;
-          fb[i] = *reinterpret_cast<const s8_t*>(sb + rdB[i] + (((ks * 4 + g) ^ row7) << 4));
-        } else {
-          int kr = ks * 32 + 8 * g + (t >> 2);
-          int key = (t >> 2) | ((g & 1) << 2);
-          const char* base = sb + ((rdB[i] ^ key) << 5) + (t & 3) * 8;
-          s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, base + kr * 256));
-          s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, base + (kr + 4) * 256));
-          fb[i] = s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+    for (int i = 0; i < FM; ++i) {
+      if (!TA) fa[i] = *reinterpret_cast<const s8_t*>(sa + ra[i]);
+      else {
+        s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + ra[i]));
+        s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + ra[i] + 4 * BM * 2));
+        fa[i] = s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa[i]), acc[i][j], 0, 0, 0);
     }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      if (!TB) fb[j] = *reinterpret_cast<const s8_t*>(sb + rb[j]);
+      else {
+        s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j]));
+        s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j] + 4 * BN * 2));
+        fb[j] = s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa[i]), acc[i][j], 0, 0, 0);
   }
-  if (kt_begin >= kt_end && p.epi == EPI_ATOMIC) return;
+  if ((p.force_cfg & 16) && acc[0][0][0] != 123456.0f) return;  // tuning aid: main loop only
   // lane (t,g) holds C[m = .. + t][n = .. + 4g + r]
+  if (p.epi == EPI_ATOMIC) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epi_dispatch(p, m0 + wm + i * 16 + t, n0 + wn + j * 16 + 4 * g, acc[i][j]);
+      for (int j = 0; j < FN; ++j)
+        epi_dispatch(p, m0 + wm + i * 16 + t, n0 + wn + j * 16 + 4 * g, acc[i][j]);
+    return;
+  }
+  // Output path.  A fragment-shaped store touches 16 rows x 32 B per instruction (16 partial cache lines) and is store-issue
+  // bound — with K = 512..768 the C tile is as expensive as the whole K loop.  So accumulators go through a wave-private LDS
+  // strip (32 rows at a time, padded rows: conflict-free b128 writes) and leave as full 128/256-B row segments; bias, GELU,
+  // residual and dGELU are applied on the way out with equally coalesced aux / residual accesses.
+  constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR;
+  constexpr int EROWS = (NW * 32 * ESTR * 4 <= GEMM_STAGES * STAGE) ? 32 : 16;  // strip height that fits the staging ring
+  static_assert(NW * EROWS * ESTR * 4 <= GEMM_STAGES * STAGE, "epilogue strip must fit the staging ring");
+  __syncthreads();
+  float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
+#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+  if (p.c_dtype == CSMAE_BF16) {
+    if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
+    else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID); else EPI_CALL(bf16_t, EPI_NONE);
+  } else {
+    if (p.epi == EPI_GELU) EPI_CALL(float, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(float, EPI_DGELU);
+    else if (p.epi == EPI_RESID) EPI_CALL(float, EPI_RESID); else EPI_CALL(float, EPI_NONE);
+  }
+#undef EPI_CALL
 }
 
 // ------------------------------------------------------------------------------------ fp32 exact
@@ -253,12 +341,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     __syncthreads();
   }
   if (kt_begin >= kt_end && p.epi == EPI_ATOMIC) return;
+  if (p.epi == EPI_SPLIT) p.C = reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     epi_dispatch(p, m0 + ty * 4 + i, n0 + tx * 4, f4_t{acc[i][0], acc[i][1], acc[i][2], acc[i][3]});
 }
 
 // ------------------------------------------------------------------------------------ C ABI
+static int g_force_cfg = -1;  // tuning hook (tools/gemm_bench.py): -1 = heuristic
+extern "C" int csmae_gemm_force_tile(int cfg) { g_force_cfg = cfg; return 0; }
+
 extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long long K,
                           const void* A, long long lda, const void* B, long long ldb,
                           void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
@@ -266,18 +358,22 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
                           int splitk, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0, "csmae_gemm: empty problem M=%lld N=%lld K=%lld", M, N, K);
   CSMAE_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "csmae_gemm: N and ldc must be multiples of 4 (N=%lld ldc=%lld)", N, ldc);
-  CSMAE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_ATOMIC, "csmae_gemm: bad epilogue %d", epilogue);
-  CSMAE_REQUIRE(epilogue != EPI_ATOMIC || c_dtype == CSMAE_F32, "csmae_gemm: atomic accumulate needs fp32 C");
+  CSMAE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_SPLIT, "csmae_gemm: bad epilogue %d", epilogue);
+  CSMAE_REQUIRE((epilogue != EPI_ATOMIC && epilogue != EPI_SPLIT) || c_dtype == CSMAE_F32, "csmae_gemm: split-K accumulate needs fp32 C");
   CSMAE_REQUIRE(!(epilogue == EPI_GELU || epilogue == EPI_DGELU) || (aux && ldaux % 4 == 0), "csmae_gemm: gelu epilogues need aux");
   CSMAE_REQUIRE(epilogue != EPI_RESID || (resid && ldr % 4 == 0), "csmae_gemm: residual epilogue needs resid");
-  CSMAE_REQUIRE(splitk >= 1 && (splitk == 1 || epilogue == EPI_ATOMIC), "csmae_gemm: split-K only with atomic accumulate");
+  CSMAE_REQUIRE(splitk >= 1 && (splitk == 1 || epilogue == EPI_ATOMIC || epilogue == EPI_SPLIT), "csmae_gemm: split-K only with the accumulate epilogues");
   GemmArgs p;
-  p.A = A; p.B = B; p.C = C; p.bias = (epilogue == EPI_ATOMIC || epilogue == EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
+  p.force_cfg = g_force_cfg;
+  p.split_stride = M * ldc;
+  p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMAE_BF16) {
-    CSMAE_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && K % 8 == 0, "csmae_gemm(bf16): lda, ldb, K must be multiples of 8 (lda=%lld ldb=%lld K=%lld)", lda, ldb, K);
+    CSMAE_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "csmae_gemm(bf16): lda and ldb must be multiples of 8 (lda=%lld ldb=%lld)", lda, ldb);
+    // K-contiguous operands are fetched in 8-element K chunks; K-strided ones are zero-filled by whole rows, any K works
+    CSMAE_REQUIRE((transA && transB) || K % 8 == 0, "csmae_gemm(bf16): K must be a multiple of 8 unless both operands are K-strided (K=%lld)", K);
     CSMAE_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "csmae_gemm(bf16): A, B, C must be 16-byte aligned");
     // K-strided operands are fetched in 8-column chunks: the row allocation must cover the rounded-up width
     CSMAE_REQUIRE(!transA || lda >= (M + 7) / 8 * 8, "csmae_gemm(bf16): transposed A needs lda >= roundup8(M)");
@@ -285,14 +381,27 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     long long abytes = (transA ? K : M) * lda * 2, bbytes = (transB ? K : N) * ldb * 2;
     CSMAE_REQUIRE(abytes < 0xFFFFFFF0ll && bbytes < 0xFFFFFFF0ll, "csmae_gemm(bf16): operand larger than 4 GiB");
     p.a_bytes = (unsigned)abytes; p.b_bytes = (unsigned)bbytes;
-    p.tiles_m = cdiv(M, 128); p.tiles_n = cdiv(N, 128); p.ktiles = cdiv(K, 64);
+    p.ktiles = cdiv(K, GEMM_BK);
+    // tile choice: as large as keeps >= ~1.5 rounds of the 256 CUs busy (bytes staged per flop ~ 1/BM + 1/BN)
+    // tile choice (measured on the step's shapes, tools/gemm_bench.py): 256x256 wins whenever it fits, also when it leaves
+    // fewer tiles than CUs (N = 768 outputs: 150 tiles) because it halves the bytes staged per flop; 256x128 never won.
+    int cfg = (M >= 256 && N >= 256) ? 2 : 0;  // 0: 128x128 (4 waves, 2 blocks/CU)  2: 256x256 (8 waves, 1 block/CU)
+    int stg = 4;
+    if (p.force_cfg >= 0) cfg = (p.force_cfg & 3) == 2 ? 2 : 0; else p.force_cfg = 0;
+    (void)stg;
+    const int bm = cfg == 0 ? 128 : 256, bn = cfg == 2 ? 256 : 128;
+    p.tiles_m = cdiv(M, bm); p.tiles_n = cdiv(N, bn);
     p.ktiles_per_split = cdiv(p.ktiles, splitk);
     p.splitk = cdiv(p.ktiles, p.ktiles_per_split);
-    dim3 grid(p.tiles_m * p.tiles_n * p.splitk), block(256);
-    if (!transA && !transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, st, p);
-    else if (!transA && transB) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, p);
-    else if (transA && transB) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, p);
+    dim3 grid(p.tiles_m * p.tiles_n * p.splitk);
+#define LAUNCH_CFG(TA_, TB_)                                                                                              \
+    if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4>), grid, dim3(512), 0, st, p);       \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4>), grid, dim3(256), 0, st, p);
+    if (!transA && !transB) { LAUNCH_CFG(false, false) }
+    else if (!transA && transB) { LAUNCH_CFG(false, true) }
+    else if (transA && transB) { LAUNCH_CFG(true, true) }
+    else { LAUNCH_CFG(true, false) }
+#undef LAUNCH_CFG
   } else if (dtype == CSMAE_F32) {
     p.a_bytes = p.b_bytes = 0;
     p.tiles_m = cdiv(M, 64); p.tiles_n = cdiv(N, 64); p.ktiles = cdiv(K, 16);
@@ -308,4 +417,35 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     return CSMAE_ERR_UNSUPPORTED;
   }
   return csmae_check_launch("csmae_gemm");
+}
+
+// ------------------------------------------------------------------------------------ weight gradients
+// dW[M=out, N=in] += dY^T X with the token axis (K = 12 800 .. 65 792) split over the whole chip.  Each slice stores its fp32
+// tile to a workspace slab with plain coalesced stores; one small kernel then folds the slabs into dW.  (The first version
+// accumulated slices with fp32 atomics: 12 M L2 atomics per GEMM cost more than the GEMM itself.)
+__global__ __launch_bounds__(256) void dw_reduce_kernel(long long n4, int S, long long slab4, const f4_t* __restrict__ ws, f4_t* __restrict__ dw) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f4_t a = dw[i];
+    for (int s = 0; s < S; ++s) a += ws[s * slab4 + i];
+    dw[i] = a;
+  }
+}
+extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
+                             float* dW, float* workspace, long long ws_elems, void* stream) {
+  CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && workspace && ws_elems >= M * N, "csmae_gemm_dw: bad arguments / workspace too small");
+  const int tile = dtype == CSMAE_BF16 ? ((M >= 256 && N >= 256) ? 256 : 128) : 64, kt = dtype == CSMAE_BF16 ? GEMM_BK : 16;
+  const long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile), ktiles = cdiv(K, kt);
+  const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? 256 : 512) : 2048;
+  long long S = slots / tiles;
+  if (S > ktiles / 6) S = ktiles / 6;
+  if (S > ws_elems / (M * N)) S = ws_elems / (M * N);
+  if (S < 1) S = 1;
+  const int kps = cdiv(ktiles, S);
+  S = cdiv(ktiles, kps);
+  int rc = csmae_gemm(dtype, 1, 1, M, N, K, dY, ldy, X, ldx, workspace, N, CSMAE_F32, nullptr, EPI_SPLIT, nullptr, 0, nullptr, 0, (int)S, stream);
+  if (rc) return rc;
+  const long long n4 = M * N / 4;
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)fmin((double)cdiv(n4, 256), 2048.0)), dim3(256), 0, (hipStream_t)stream, n4, (int)S, n4,
+                     reinterpret_cast<const f4_t*>(workspace), reinterpret_cast<f4_t*>(dW));
+  return csmae_check_launch("csmae_gemm_dw");
 }

@@ -26,7 +26,7 @@ extern "C" {
 #define CSMAE_BF16 1
 
 enum csmae_status { CSMAE_OK = 0, CSMAE_ERR_ARG = -1, CSMAE_ERR_LAUNCH = -2, CSMAE_ERR_UNSUPPORTED = -3 };
-enum csmae_epilogue { CSMAE_EPI_NONE = 0, CSMAE_EPI_GELU = 1, CSMAE_EPI_RESID = 2, CSMAE_EPI_DGELU = 3, CSMAE_EPI_ATOMIC = 4 };
+enum csmae_epilogue { CSMAE_EPI_NONE = 0, CSMAE_EPI_GELU = 1, CSMAE_EPI_RESID = 2, CSMAE_EPI_DGELU = 3, CSMAE_EPI_ATOMIC = 4, CSMAE_EPI_SPLIT = 5 };
 enum csmae_loss { CSMAE_LOSS_MSE = 0, CSMAE_LOSS_L2 = 1, CSMAE_LOSS_MAE = 2, CSMAE_LOSS_L1 = 3, CSMAE_LOSS_BCE = 4 };
 
 const char* csmae_last_error(void);
@@ -41,6 +41,13 @@ int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long
                const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int c_dtype,
                const float* bias, int epilogue, void* aux, long long ldaux, const float* resid, long long ldr,
                int splitk, void* stream);
+
+/* weight gradient of nn.Linear: dW[M=out,N=in] (fp32, contiguous) += dY[K,M]^T X[K,N]; token axis split over the chip into fp32 slabs in
+ * `workspace` (>= M*N floats; more = more slices), folded by a deterministic reduce (util/misc.py:314 backward products). */
+int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
+                  float* dW, float* workspace, long long ws_elems, void* stream);
+/* tuning hook for tools/gemm_bench.py: force the bf16 block tile (0: 128x128, 1: 256x128, 2: 256x256, -1: heuristic) */
+int csmae_gemm_force_tile(int cfg);
 
 /* ---- softmax attention of timm Block (Attention.forward: softmax(q k^T * hd^-0.5) v), qkv is [B*T, 3*H*hd]
  * in timm's (3, H, hd) column order; out [B*T, H*hd]; lse [B, H, T] (natural log). */

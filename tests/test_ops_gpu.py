@@ -99,6 +99,23 @@ def test_gemm_epilogues(ops, dtype):
     assert_close(acc, acc0 + dY.float().t() @ X.float(), 1e-4, 1e-3, "atomic splitk")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("mnk", [(768, 512, 4000), (64, 48, 1000), (2304, 768, 2560), (256, 256, 300), (520, 264, 77 * 8)])
+def test_gemm_dw_split_slabs(ops, dtype, mnk):
+    M, N, K = mnk
+    dY, X = rnd(K, M, seed=12).to(dtype), rnd(K, N, seed=13).to(dtype)
+    acc0 = rnd(M, N, seed=14)
+    acc = dev(acc0.clone())
+    ws = torch.empty(max(M * N * 3, 1 << 20), device="cuda")
+    ops.gemm_dw(dev(dY), dev(X), acc, ws)
+    assert_close(acc, acc0 + dY.float().t() @ X.float(), 1e-4, 1e-3 * K ** 0.5 / 30, f"gemm_dw {mnk}")
+    # padded operands (ld > width), as the patch-embed / decoder_pred gradients use
+    dYp = torch.zeros(K, M + 8, dtype=dtype); dYp[:, :M] = dY
+    acc = dev(acc0.clone())
+    ops.gemm_dw(dev(dYp)[:, :M], dev(X), acc, ws)
+    assert_close(acc, acc0 + dY.float().t() @ X.float(), 1e-4, 1e-3 * K ** 0.5 / 30, "gemm_dw padded")
+
+
 def test_gemm_rejects_bad_args(ops):
     import csmae_hip
     a = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)  # K = 12 not a multiple of 8
