@@ -21,12 +21,12 @@ LIB_PATH = os.path.join(_HERE, "libcsmae_hip.so")
 I, L, P, F = c_int, c_longlong, c_void_p, c_float
 _SIGNATURES = {
     "csmae_gemm": [I, I, I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, I, P],
-    "csmae_gemm_dw": [I, L, L, L, P, L, P, L, P, P, L, P],
+    "csmae_gemm_dw": [I, L, L, L, P, L, P, L, P, P, P, L, P],
     "csmae_gemm_force_tile": [I],
     "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
     "csmae_layernorm_fwd": [I, L, I, P, P, P, F, P, P, P, P, P],
-    "csmae_layernorm_bwd": [I, I, L, I, P, P, P, P, P, P, P, P, P, P, P],
+    "csmae_layernorm_bwd": [I, I, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P],
     "csmae_bnrelu_fwd": [I, I, I, I, P, P, P, F, F, P, P, P, P, P, P, I, P],
     "csmae_bnrelu_bwd": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "csmae_crop_resize": [L, I, P, P, P, P],

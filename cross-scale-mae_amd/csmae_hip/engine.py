@@ -172,6 +172,7 @@ class Workspace:
         self.demb = E(Md, Dd, **f32)
         self.dz_lp = E(Me, Dd, **lp)
         self.dtok_lp = E(B2 * max(keep, 1), D, **lp)
+        self.ln_ws = E(1024 * 2 * max(D, Dd), **f32)  # per-block dgamma/dbeta partial rows of LayerNorm backward
         self.dw_ws = E(64 * 1024 * 1024, **f32)  # split-K slabs of the weight-gradient GEMMs (256 MiB)
 
 
@@ -240,8 +241,7 @@ class Engine:
         tile, kt = (128, 64) if self.T == BF16 else (64, 16)
         sk = self._splitk(gw2.shape[0], gw2.shape[1], dy.shape[0], tile, kt)
         dyv, xv = dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]]
-        ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, st=self.st)
-        ops.colsum(dyv, self.flat.G(name + ".bias"), st=self.st)
+        ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, db=self.flat.G(name + ".bias"), st=self.st)
 
     # ------------------------------------------------------------------ transformer block
     def _block_fwd(self, S, i, pre, M, Dm, H, B2, T):
@@ -269,14 +269,14 @@ class Engine:
         self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
         ops.gemm(dpre, self.W(pre + "mlp.fc1.weight"), t1, trans_b=True, st=st)
         ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, G(pre + "norm2.weight"), G(pre + "norm2.bias"),
-                          dres_in=dres, dx_lp=dres_lp, st=st)
+                          dres_in=dres, dx_lp=dres_lp, partial_ws=ws.ln_ws, st=st)
         self._dw(dres_lp, S["o"][i], pre + "attn.proj")
         ops.gemm(dres_lp, self.W(pre + "attn.proj.weight"), t1, trans_b=True, st=st)
         ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
         self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
         ops.gemm(dqkv, self.W(pre + "attn.qkv.weight"), t1, trans_b=True, st=st)
         ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, G(pre + "norm1.weight"), G(pre + "norm1.bias"),
-                          dres_in=dres, dx_lp=dres_lp, st=st)
+                          dres_in=dres, dx_lp=dres_lp, partial_ws=ws.ln_ws, st=st)
 
     # ------------------------------------------------------------------ forward
     def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool):
@@ -383,7 +383,7 @@ class Engine:
             ops.rows_scatter_add(ws.dpin, ws.demb, L, Td, N * Td + 1, st=st)
         # decoder
         ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d,
-                          G("decoder_norm.weight"), G("decoder_norm.bias"), dx_lp=ws.dres_d_lp, st=st)
+                          G("decoder_norm.weight"), G("decoder_norm.bias"), dx_lp=ws.dres_d_lp, partial_ws=ws.ln_ws, st=st)
         for i in reversed(range(c["Nd"])):
             self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp)
         ops.unshuffle_bwd(ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
@@ -408,8 +408,7 @@ class Engine:
             if dp is not None:
                 dp.grads_ready(self.flat, ("enc", i))
         ops.embed_assemble_bwd(ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
-        ops.gemm_dw(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), ws.dw_ws, st=st)
-        ops.colsum(ws.dtok_lp, G("patch_embed.proj.bias"), st=st)
+        ops.gemm_dw(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), ws.dw_ws, db=G("patch_embed.proj.bias"), st=st)
         if dp is not None:
             dp.grads_ready(self.flat, "stem")
             dp.backward_done(self.flat)

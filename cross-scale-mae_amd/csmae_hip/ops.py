@@ -78,14 +78,14 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NON
     return out
 
 
-def gemm_dw(dy, x, dw, workspace, st=None):
-    """dw[out,in] (fp32, contiguous) += dy[tokens,out]^T x[tokens,in] via split-K slabs in `workspace` (fp32)."""
+def gemm_dw(dy, x, dw, workspace, db=None, st=None):
+    """dw[out,in] (fp32, contiguous) += dy[tokens,out]^T x[tokens,in] via split-K slabs in `workspace` (fp32); db[out] += colsum(dy)."""
     K, M = dy.shape
     N = x.shape[1]
     assert x.shape[0] == K and dw.shape == (M, N) and dw.is_contiguous() and dy.dtype == x.dtype
     if _timer is not None:
         _timer.begin()
-    check(load().csmae_gemm_dw(dt(dy), M, N, K, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(workspace), workspace.numel(),
+    check(load().csmae_gemm_dw(dt(dy), M, N, K, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), _p(db), _p(workspace), workspace.numel(),
                                st if st is not None else stream()), "csmae_gemm_dw")
     if _timer is not None:
         _timer.end(("gemm_bf16" if dy.dtype == torch.bfloat16 else "gemm_f32") + "_TN", 2.0 * M * N * K)
@@ -105,11 +105,12 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, y32=None, eps=1e-6, st=None):
                                      st if st is not None else stream()), "csmae_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx_out, dgamma, dbeta, dres_in=None, dx_lp=None, st=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_out, dgamma, dbeta, dres_in=None, dx_lp=None, partial_ws=None, st=None):
     M, D = x.shape
     lp = dt(dx_lp) if dx_lp is not None else dt(dy)
     check(load().csmae_layernorm_bwd(dt(dy), lp, M, D, _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres_in), _p(dx_out), _p(dx_lp),
-                                     _p(dgamma), _p(dbeta), st if st is not None else stream()), "csmae_layernorm_bwd")
+                                     _p(dgamma), _p(dbeta), _p(partial_ws), partial_ws.numel() if partial_ws is not None else 0,
+                                     st if st is not None else stream()), "csmae_layernorm_bwd")
 
 
 def bnrelu_fwd(u, gamma, beta, r, mean, rstd, N, L, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, training=True, st=None):

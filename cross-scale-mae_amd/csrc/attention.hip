@@ -54,12 +54,14 @@ template <int HD, int NKF>
 __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                      float* __restrict__ lse, int T, int H, int D, int hd, float scale) {
   constexpr int TP = NKF * 16, KS = HD / 32, DF = HD / 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TP * AttnLds<HD>::STRIDE];
+  __shared__ __attribute__((aligned(16))) char smem[3 * TP * AttnLds<HD>::STRIDE];
   char* Ks = smem;
   char* Vs = smem + TP * AttnLds<HD>::STRIDE;
+  char* Qs = smem + 2 * TP * AttnLds<HD>::STRIDE;  // Q too: a per-q-block global fetch would expose ~1 us of latency per block
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
+  stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);
   stage_head<HD, TP>(Ks, qkv, row0, ld, D + h * hd, T, hd);
   stage_head<HD, TP>(Vs, qkv, row0, ld, 2 * D + h * hd, T, hd);
   __syncthreads();
@@ -70,12 +72,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
     const int q = qb * 16 + t;
     s8_t fq[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      int d = ks * 32 + 8 * g;
-      if (q < T && d < hd) v = *reinterpret_cast<const uint4*>(qkv + (row0 + q) * ld + h * hd + d);
-      fq[ks] = __builtin_bit_cast(s8_t, v);
-    }
+    for (int ks = 0; ks < KS; ++ks) fq[ks] = frag_rows<HD>(Qs, qb * 16, ks, t, g);
     f4_t s[NKF];
     float m = -INFINITY;
 #pragma unroll
@@ -83,12 +80,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
       f4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) a = MFMA16(frag_rows<HD>(Ks, f * 16, ks, t, g), fq[ks], a);
+      a *= c2;
+      if (f * 16 + 16 > T) {  // only the trailing fragment(s) hold padded keys (wave-uniform test)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = f * 16 + 4 * g + r;
-        a[r] = key < T ? a[r] * c2 : -INFINITY;
-        m = fmaxf(m, a[r]);
+        for (int r = 0; r < 4; ++r) if (f * 16 + 4 * g + r >= T) a[r] = -INFINITY;
       }
+      m = fmaxf(fmaxf(m, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
       s[f] = a;
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -97,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
 #pragma unroll
     for (int f = 0; f < NKF; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { float p = exp2f(s[f][r] - m); s[f][r] = p; l += p; }
+      for (int r = 0; r < 4; ++r) { float p = __builtin_amdgcn_exp2f(s[f][r] - m); s[f][r] = p; l += p; }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
@@ -139,7 +136,19 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
       l2 = lse[((long long)b * H + h) * T + r] * LOG2E;
       const bf16_t* o = out + (row0 + r) * D + h * hd;
       const bf16_t* gg = dout + (row0 + r) * D + h * hd;
-      for (int d = 0; d < hd; d += 4) { f4_t a = ld4<bf16_t>(o + d), c = ld4<bf16_t>(gg + d); acc += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3]; }
+      uint4 ov[HD / 8], gv[HD / 8];
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        ov[c] = c * 8 < hd ? *reinterpret_cast<const uint4*>(o + c * 8) : make_uint4(0, 0, 0, 0);
+        gv[c] = c * 8 < hd ? *reinterpret_cast<const uint4*>(gg + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        const unsigned ow[4] = {ov[c].x, ov[c].y, ov[c].z, ov[c].w}, gw[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          acc += __uint_as_float(ow[k] << 16) * __uint_as_float(gw[k] << 16) + __uint_as_float(ow[k] & 0xffff0000u) * __uint_as_float(gw[k] & 0xffff0000u);
+      }
     }
     lse2[r] = l2; dl[r] = acc;
   }
@@ -167,9 +176,12 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
       f4_t ds;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int key = f * 16 + 4 * g + r;
-        float p = key < T ? exp2f(a[r] * c2 - my_l2) : 0.f;
+        float p = __builtin_amdgcn_exp2f(a[r] * c2 - my_l2);
         ds[r] = p * (dp[r] - my_dl) * scale;
+      }
+      if (f * 16 + 16 > T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (f * 16 + 4 * g + r >= T) ds[r] = 0.f;
       }
       if (f & 1) fds[f >> 1] = pack_pair(prev, ds); else prev = ds;
     }
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
       f4_t p, ds;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[r] = exp2f(a[r] * c2 - l4[r]);  // padded queries have lse2 = +inf -> p = 0
+        p[r] = __builtin_amdgcn_exp2f(a[r] * c2 - l4[r]);  // padded queries have lse2 = +inf -> p = 0
         ds[r] = p[r] * (dp[r] - d4[r]) * scale;
       }
       if (f & 1) { fp[f >> 1] = pack_pair(prev_p, p); fds[f >> 1] = pack_pair(prev_ds, ds); } else { prev_p = p; prev_ds = ds; }

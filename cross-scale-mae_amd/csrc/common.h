@@ -34,13 +34,11 @@ int csmae_check_launch(const char* what);
 
 // ---- scalar conversions (round-to-nearest-even, NaN preserved)
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+// native conversions: hipcc lowers them to gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserving) — one instruction
+// per PAIR instead of the ~8-instruction integer sequence
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { bf2_t v = {(__bf16)lo, (__bf16)hi}; return __builtin_bit_cast(unsigned, v); }
 
 template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p);
 template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p) { return *p; }
@@ -117,6 +115,29 @@ template <typename T> __device__ __forceinline__ float gelu_bwd(float x);
 template <> __device__ __forceinline__ float gelu_bwd<float>(float x) { return gelu_erf_grad(x); }
 template <> __device__ __forceinline__ float gelu_bwd<bf16_t>(float x) {
   return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// GELU and its derivative from ONE exponential: e = exp(-x^2/2) feeds both erf (A&S 7.1.26: erfc(z) = t*poly(t)*exp(-z^2),
+// z = |x|/sqrt2) and the Gaussian density.  The fc1 epilogue stores h = gelu(x) and g = gelu'(x); the fc2-backward epilogue is then
+// a single multiply (it used to recompute erf + exp from the saved pre-activation).
+template <typename T> __device__ __forceinline__ void gelu_both(float x, float& h, float& gp);
+template <> __device__ __forceinline__ void gelu_both<bf16_t>(float x, float& h, float& gp) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.0f));  // 0.3275911 / sqrt(2)
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-0.72134752f * x * x);          // exp(-x^2/2)
+  const float q = 0.5f * poly * t * e;                                   // 0.5*erfc(|x|/sqrt2) = Phi(-|x|)
+  const float phi = x >= 0.f ? 1.0f - q : q;                             // Phi(x)
+  h = x * phi;
+  gp = fmaf(x * 0.39894228f, e, phi);
+}
+template <> __device__ __forceinline__ void gelu_both<float>(float x, float& h, float& gp) { h = gelu_erf(x); gp = gelu_erf_grad(x); }
+template <typename T> __device__ __forceinline__ void gelu_both4(f4_t x, f4_t& h, f4_t& gp) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { float a, b; gelu_both<T>(x[k], a, b); h[k] = a; gp[k] = b; }
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -19,9 +19,9 @@
 #include "common.h"
 
 #define EPI_NONE 0    // C = acc + bias
-#define EPI_GELU 1    // aux = acc + bias ; C = gelu(aux)
+#define EPI_GELU 1    // x = acc + bias ; C = gelu(x) ; aux = gelu'(x)
 #define EPI_RESID 2   // C = acc + bias + resid (resid fp32)
-#define EPI_DGELU 3   // C = acc * gelu'(aux)
+#define EPI_DGELU 3   // C = acc * aux   (aux = gelu'(x) saved by the forward epilogue)
 #define EPI_ATOMIC 4  // C(fp32) += acc   (split-K, atomics)
 #define EPI_SPLIT 5   // C(fp32)[split] = acc  (split-K partial slabs, reduced by dw_reduce_kernel: deterministic, no atomics)
 
@@ -33,6 +33,7 @@ struct GemmArgs {
   unsigned a_bytes, b_bytes;
   int force_cfg;
   long long split_stride;
+  float* colsum;  // K-strided-A kernels only: slab [splitk][M] receiving sum_k A(m,k) (the bias gradient of nn.Linear)
 };
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -40,17 +41,16 @@ template <typename TC>
 __device__ __forceinline__ void epi_store4(const GemmArgs& p, int m, int n, f4_t v) {
   if (p.bias) { f4_t b = *reinterpret_cast<const f4_t*>(p.bias + n); v += b; }
   TC* c = reinterpret_cast<TC*>(p.C) + (long long)m * p.ldc + n;
-  if (p.epi == EPI_GELU) {
-    // the saved pre-activation is what backward sees: evaluate gelu on the value as stored (rounded for bf16)
-    v = round4<TC>(v);
-    st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)m * p.ldaux + n, v);
-    v[0] = gelu_fwd<TC>(v[0]); v[1] = gelu_fwd<TC>(v[1]); v[2] = gelu_fwd<TC>(v[2]); v[3] = gelu_fwd<TC>(v[3]);
+  if (p.epi == EPI_GELU) {  // aux <- gelu'(pre) (what backward multiplies by), C <- gelu(pre)
+    f4_t gp;
+    const f4_t x = v;
+    gelu_both4<TC>(x, v, gp);
+    st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)m * p.ldaux + n, gp);
   } else if (p.epi == EPI_RESID) {
     f4_t r = *reinterpret_cast<const f4_t*>(p.resid + (long long)m * p.ldr + n);
     v += r;
   } else if (p.epi == EPI_DGELU) {
-    f4_t q = ld4<TC>(reinterpret_cast<const TC*>(p.aux) + (long long)m * p.ldaux + n);
-    v[0] *= gelu_bwd<TC>(q[0]); v[1] *= gelu_bwd<TC>(q[1]); v[2] *= gelu_bwd<TC>(q[2]); v[3] *= gelu_bwd<TC>(q[3]);
+    v *= ld4<TC>(reinterpret_cast<const TC*>(p.aux) + (long long)m * p.ldaux + n);
   }
   st4<TC>(c, v);
 }
@@ -143,14 +143,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f4_t (&acc)[FM]
     for (int ps = 0; ps < NPASS; ++ps) {
       const int gm = mbase + part * EROWS + ps * RPP + rsub;
       f4_t v = *reinterpret_cast<const f4_t*>(ew + (ps * RPP + rsub) * ESTR + col) + bias4;
-      if (EPI == EPI_GELU) v = round4<TC>(v);  // backward sees the stored (rounded) pre-activation: evaluate gelu on exactly that value
       f4_t o = v;
-      if (EPI == EPI_GELU) { o[0] = gelu_fwd<TC>(v[0]); o[1] = gelu_fwd<TC>(v[1]); o[2] = gelu_fwd<TC>(v[2]); o[3] = gelu_fwd<TC>(v[3]); }
-      if (EPI == EPI_RESID) o = v + ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
-      if (EPI == EPI_DGELU) {
-        const f4_t x = ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
-        o[0] = v[0] * gelu_bwd<TC>(x[0]); o[1] = v[1] * gelu_bwd<TC>(x[1]); o[2] = v[2] * gelu_bwd<TC>(x[2]); o[3] = v[3] * gelu_bwd<TC>(x[3]);
+      if (EPI == EPI_GELU) {  // o = gelu(v); v <- gelu'(v), the factor the backward epilogue multiplies by
+        const f4_t x = v;
+        gelu_both4<TC>(x, o, v);
       }
+      if (EPI == EPI_RESID) o = v + ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
+      if (EPI == EPI_DGELU) o = v * ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
       if (colok && gm < p.M) {
         if (EPI == EPI_GELU) st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)gm * p.ldaux + gn, v);
         st4<TC>(reinterpret_cast<TC*>(p.C) + (long long)gm * p.ldc + gn, o);
@@ -213,6 +212,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
   const int wm = (w / NWN) * WM, wn = (w % NWN) * WN;
+  // bias gradient for free: on the tn == 0 column of tiles the waves owning wn == 0 run one extra MFMA per A fragment against
+  // an all-ones operand, i.e. sum_k A(m,k), instead of a separate pass that re-reads dY from HBM
+  const bool do_cs = TA && TB && p.colsum != nullptr && tn == 0 && wn == 0;
+  f4_t accb[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) accb[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const s8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   // per-lane fragment offsets inside an operand image
   int ra[FM], rb[FN];
@@ -265,6 +271,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa[i]), acc[i][j], 0, 0, 0);
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, ones), __builtin_bit_cast(bf8_t, fa[i]), accb[i], 0, 0, 0);
+    }
+  }
+  if (do_cs && g == 0) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm + i * 16 + t;
+      if (m < p.M) p.colsum[(long long)split * p.M + m] = accb[i][0];
+    }
   }
   if ((p.force_cfg & 16) && acc[0][0][0] != 123456.0f) return;  // tuning aid: main loop only
   // lane (t,g) holds C[m = .. + t][n = .. + 4g + r]
@@ -366,6 +384,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
   GemmArgs p;
   p.force_cfg = g_force_cfg;
   p.split_stride = M * ldc;
+  p.colsum = (epilogue == EPI_SPLIT && transA && transB && dtype == CSMAE_BF16) ? reinterpret_cast<float*>(aux) : nullptr;
   p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;
@@ -423,29 +442,40 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
 // dW[M=out, N=in] += dY^T X with the token axis (K = 12 800 .. 65 792) split over the whole chip.  Each slice stores its fp32
 // tile to a workspace slab with plain coalesced stores; one small kernel then folds the slabs into dW.  (The first version
 // accumulated slices with fp32 atomics: 12 M L2 atomics per GEMM cost more than the GEMM itself.)
-__global__ __launch_bounds__(256) void dw_reduce_kernel(long long n4, int S, long long slab4, const f4_t* __restrict__ ws, f4_t* __restrict__ dw) {
+__global__ __launch_bounds__(256) void dw_reduce_kernel(long long n4, int S, long long slab4, const f4_t* __restrict__ ws, f4_t* __restrict__ dw,
+                                                        const float* __restrict__ wsb, float* __restrict__ db, int M) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f4_t a = dw[i];
     for (int s = 0; s < S; ++s) a += ws[s * slab4 + i];
     dw[i] = a;
   }
+  if (db && blockIdx.x == 0)
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+      float a = db[m];
+      for (int s = 0; s < S; ++s) a += wsb[(long long)s * M + m];
+      db[m] = a;
+    }
 }
+extern int csmae_colsum_launch(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream);
 extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
-                             float* dW, float* workspace, long long ws_elems, void* stream) {
-  CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && workspace && ws_elems >= M * N, "csmae_gemm_dw: bad arguments / workspace too small");
+                             float* dW, float* db, float* workspace, long long ws_elems, void* stream) {
+  CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && workspace && ws_elems >= M * N + M, "csmae_gemm_dw: bad arguments / workspace too small");
   const int tile = dtype == CSMAE_BF16 ? ((M >= 256 && N >= 256) ? 256 : 128) : 64, kt = dtype == CSMAE_BF16 ? GEMM_BK : 16;
   const long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile), ktiles = cdiv(K, kt);
   const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? 256 : 512) : 2048;
   long long S = slots / tiles;
   if (S > ktiles / 6) S = ktiles / 6;
-  if (S > ws_elems / (M * N)) S = ws_elems / (M * N);
+  if (S > ws_elems / (M * N + M)) S = ws_elems / (M * N + M);
   if (S < 1) S = 1;
   const int kps = cdiv(ktiles, S);
   S = cdiv(ktiles, kps);
-  int rc = csmae_gemm(dtype, 1, 1, M, N, K, dY, ldy, X, ldx, workspace, N, CSMAE_F32, nullptr, EPI_SPLIT, nullptr, 0, nullptr, 0, (int)S, stream);
+  float* wsb = workspace + S * M * N;  // bias-gradient slab [S][M] (filled by the bf16 kernel's ones-operand MFMAs)
+  const bool fused_bias = db && dtype == CSMAE_BF16;
+  int rc = csmae_gemm(dtype, 1, 1, M, N, K, dY, ldy, X, ldx, workspace, N, CSMAE_F32, nullptr, EPI_SPLIT, fused_bias ? wsb : nullptr, 0, nullptr, 0, (int)S, stream);
   if (rc) return rc;
   const long long n4 = M * N / 4;
   hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)fmin((double)cdiv(n4, 256), 2048.0)), dim3(256), 0, (hipStream_t)stream, n4, (int)S, n4,
-                     reinterpret_cast<const f4_t*>(workspace), reinterpret_cast<f4_t*>(dW));
+                     reinterpret_cast<const f4_t*>(workspace), reinterpret_cast<f4_t*>(dW), wsb, fused_bias ? db : nullptr, (int)M);
+  if (db && !fused_bias) return csmae_colsum_launch(dtype, K, (int)M, dY, ldy, db, stream);
   return csmae_check_launch("csmae_gemm_dw");
 }

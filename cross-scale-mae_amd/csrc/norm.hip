@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres_in,
                                                      float* __restrict__ dx_out, TLP* __restrict__ dx_lp,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part) {
   __shared__ float red[4 * 64 * 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nv = D >> 2;
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
     if (w == 0 && c < nv) {
       f4_t s = *reinterpret_cast<f4_t*>(red + lane * 4) + *reinterpret_cast<f4_t*>(red + (64 + lane) * 4) +
                *reinterpret_cast<f4_t*>(red + (128 + lane) * 4) + *reinterpret_cast<f4_t*>(red + (192 + lane) * 4);
-      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dgamma + c * 4 + k, s[k]);
+      if (part) *reinterpret_cast<f4_t*>(part + (long long)blockIdx.x * 2 * D + c * 4) = s;
+      else for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dgamma + c * 4 + k, s[k]);
     }
     __syncthreads();
     *reinterpret_cast<f4_t*>(red + (w * 64 + lane) * 4) = ab[i];
@@ -107,8 +108,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
     if (w == 0 && c < nv) {
       f4_t s = *reinterpret_cast<f4_t*>(red + lane * 4) + *reinterpret_cast<f4_t*>(red + (64 + lane) * 4) +
                *reinterpret_cast<f4_t*>(red + (128 + lane) * 4) + *reinterpret_cast<f4_t*>(red + (192 + lane) * 4);
-      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dbeta + c * 4 + k, s[k]);
+      if (part) *reinterpret_cast<f4_t*>(part + (long long)blockIdx.x * 2 * D + D + c * 4) = s;
+      else for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dbeta + c * 4 + k, s[k]);
     }
+  }
+}
+
+// dgamma/dbeta: per-block partial rows -> one column sum per thread (same-address L2 atomics from 1024 blocks serialise:
+// they cost 3x the kernel's HBM time in the first version)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(int nblk, int D, const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (c < 2 * D)
+    for (int b = blockIdx.y * 4 + ty; b < nblk; b += gridDim.y * 4) s += part[(long long)b * 2 * D + c];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < 2 * D) {
+    s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    unsafeAtomicAdd(c < D ? dgamma + c : dbeta + (c - D), s);  // gridDim.y-way contention only
   }
 }
 
@@ -133,24 +152,28 @@ extern "C" int csmae_layernorm_fwd(int out_dtype, long long M, int D, const floa
 
 template <typename TDY, typename TLP>
 static void ln_bwd_launch(long long M, int D, const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                          const float* dres_in, float* dx_out, void* dx_lp, float* dgamma, float* dbeta, hipStream_t st) {
+                          const float* dres_in, float* dx_out, void* dx_lp, float* dgamma, float* dbeta, float* part, long long part_elems,
+                          hipStream_t st) {
   int blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
+  if (part && part_elems / (2 * D) < blocks) blocks = (int)(part_elems / (2 * D));
+  if (blocks < 1 || !dgamma) part = nullptr, blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
   dim3 grid(blocks), block(256);
   int nv = cdiv(D, 256);
-#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, x, mean, rstd, gamma, dres_in, dx_out, (TLP*)dx_lp, dgamma, dbeta)
+#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, x, mean, rstd, gamma, dres_in, dx_out, (TLP*)dx_lp, dgamma, dbeta, part)
   switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break; case 5: LNB(5); break; default: LNB(8); }
 #undef LNB
+  if (part) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), 16), dim3(256), 0, st, blocks, D, part, dgamma, dbeta);
 }
 
 extern "C" int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int D, const void* dy, const float* x, const float* mean,
                                    const float* rstd, const float* gamma, const float* dres_in, float* dx_out, void* dx_lp,
-                                   float* dgamma, float* dbeta, void* stream) {
+                                   float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* stream) {
   CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
   hipStream_t st = (hipStream_t)stream;
-  if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_BF16) ln_bwd_launch<bf16_t, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
-  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_BF16) ln_bwd_launch<float, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
-  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_F32) ln_bwd_launch<float, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
-  else if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_F32) ln_bwd_launch<bf16_t, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, st);
+  if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_BF16) ln_bwd_launch<bf16_t, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
+  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_BF16) ln_bwd_launch<float, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
+  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_F32) ln_bwd_launch<float, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
+  else if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_F32) ln_bwd_launch<bf16_t, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
   else { csmae_set_error("csmae_layernorm_bwd: bad dtypes %d/%d", dy_dtype, lp_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_layernorm_bwd");
 }

@@ -74,7 +74,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(long long M, int N, const T
   if (ty == 0 && col < N)
     for (int k = 0; k < 4; ++k) unsafeAtomicAdd(out + col + k, red[0][tx][k] + red[1][tx][k] + red[2][tx][k] + red[3][tx][k]);
 }
+int csmae_colsum_launch(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream);
 extern "C" int csmae_colsum(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream) {
+  return csmae_colsum_launch(dtype, M, N, x, ld, out, stream);
+}
+int csmae_colsum_launch(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "csmae_colsum: N and ld must be multiples of 4");
   int gx = cdiv(N, 256), gy = (int)fmin((double)cdiv(M, 64), fmax(1.0, 1024.0 / gx));
   hipStream_t st = (hipStream_t)stream;

@@ -35,17 +35,18 @@ int csmae_abi_version(void);
 /* ---- dense contractions: nn.Linear of timm Block / decoder_embed / decoder_pred / predictor and their backward
  * (timm 0.4.12 Attention.qkv/.proj, Mlp.fc1/.fc2 — call sites models_mae/MAE_ViT_Baseline.py:160-188,270,295;
  *  models_mae/MLP.py:6,9).  C[M,N] = sum_k A(m,k) B(k,n); transX = 0: K contiguous ([M,K] / [N,K]); 1: K strided ([K,M] / [K,N]).
- *  epilogue: NONE (+bias) | GELU (aux = pre-activation, C = gelu) | RESID (C = acc + bias + resid, fp32) |
- *            DGELU (C = acc * gelu'(aux)) | ATOMIC (fp32 C += acc; split-K weight gradients). */
+ *  epilogue: NONE (+bias) | GELU (x = acc + bias: C = gelu(x), aux = gelu'(x)) | RESID (C = acc + bias + resid, fp32) |
+ *            DGELU (C = acc * aux) | ATOMIC (fp32 C += acc) | SPLIT (fp32 split-K slabs, see csmae_gemm_dw). */
 int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long long K,
                const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int c_dtype,
                const float* bias, int epilogue, void* aux, long long ldaux, const float* resid, long long ldr,
                int splitk, void* stream);
 
 /* weight gradient of nn.Linear: dW[M=out,N=in] (fp32, contiguous) += dY[K,M]^T X[K,N]; token axis split over the chip into fp32 slabs in
- * `workspace` (>= M*N floats; more = more slices), folded by a deterministic reduce (util/misc.py:314 backward products). */
+ * `workspace` (>= M*N+M floats; more = more slices), folded by a deterministic reduce; db[M] (nullable) += column sums of dY, computed
+ * inside the same kernel by an all-ones MFMA operand (util/misc.py:314 backward products). */
 int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
-                  float* dW, float* workspace, long long ws_elems, void* stream);
+                  float* dW, float* db, float* workspace, long long ws_elems, void* stream);
 /* tuning hook for tools/gemm_bench.py: force the bf16 block tile (0: 128x128, 1: 256x128, 2: 256x256, -1: heuristic) */
 int csmae_gemm_force_tile(int cfg);
 
@@ -56,12 +57,13 @@ int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv
                    const float* lse, void* dqkv, void* stream);
 
 /* ---- nn.LayerNorm(eps=1e-6) (MAE_ViT_Baseline.py:43-45): x fp32 [M,D]; y in out_dtype (+ optional fp32 copy y32).
- * bwd: dx_out = dres_in + LN'(dy); dx_lp = low-precision copy for the next GEMM; dgamma/dbeta += (atomic). */
+ * bwd: dx_out = dres_in + LN'(dy); dx_lp = low-precision copy for the next GEMM; dgamma/dbeta += via per-block partial rows in
+ * partial_ws (>= 2*D floats per block; null -> atomics). */
 int csmae_layernorm_fwd(int out_dtype, long long M, int D, const float* x, const float* gamma, const float* beta, float eps,
                         void* y, float* y32, float* mean, float* rstd, void* stream);
 int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int D, const void* dy, const float* x, const float* mean,
                         const float* rstd, const float* gamma, const float* dres_in, float* dx_out, void* dx_lp,
-                        float* dgamma, float* dbeta, void* stream);
+                        float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* stream);
 
 /* ---- predictor BatchNorm1d(num_patches) + ReLU (models_mae/MLP.py:7-8): channel = token position, batch statistics
  * over (sample, feature); updates running stats (momentum, unbiased var) and num_batches_tracked in place. */

@@ -72,8 +72,11 @@ def test_gemm_epilogues(ops, dtype):
     out, aux = torch.empty(M, N, device="cuda", dtype=dtype), torch.empty(M, N, device="cuda", dtype=dtype)
     ops.gemm(dev(A), dev(B), out, bias=dev(bias), epilogue=1, aux=aux)
     tol = 1e-5 if dtype == torch.float32 else 1e-2
-    assert_close(aux, pre, tol, tol, "gelu aux")
-    assert_close(out, torch.nn.functional.gelu(aux.float().cpu()), tol, tol, "gelu out")
+    pg = pre.clone().requires_grad_(True)
+    act = torch.nn.functional.gelu(pg)
+    act.sum().backward()
+    assert_close(aux, pg.grad, tol, tol, "gelu aux = gelu'(pre)")
+    assert_close(out, act, tol, tol, "gelu out")
     # residual: fp32 in/out
     R = rnd(M, N, seed=7)
     o32 = torch.empty(M, N, device="cuda")
@@ -83,13 +86,11 @@ def test_gemm_epilogues(ops, dtype):
     x = dev(R.clone())
     ops.gemm(dev(A), dev(B), x, bias=dev(bias), epilogue=2, resid=x)
     assert_close(x, pre + R, 1e-5 if dtype == torch.float32 else 1e-4, 1e-4, "resid in place")
-    # dGELU: out = acc * gelu'(aux)
+    # dGELU: out = acc * aux
     P = rnd(M, N, seed=8).to(dtype)
-    pf = P.float().requires_grad_(True)
-    torch.nn.functional.gelu(pf).sum().backward()
     od = torch.empty(M, N, device="cuda", dtype=dtype)
     ops.gemm(dev(A), dev(B), od, epilogue=3, aux=dev(P))
-    assert_close(od, (A.float() @ B.float().t()) * pf.grad, tol, tol, "dgelu")
+    assert_close(od, (A.float() @ B.float().t()) * P.float(), tol, tol, "dgelu")
     # atomic split-K accumulate on top of existing content (weight-gradient form: both operands K-strided)
     Kt = 1000
     dY, X = rnd(Kt, 64, seed=9).to(dtype), rnd(Kt, 48, seed=10).to(dtype)
@@ -107,8 +108,11 @@ def test_gemm_dw_split_slabs(ops, dtype, mnk):
     acc0 = rnd(M, N, seed=14)
     acc = dev(acc0.clone())
     ws = torch.empty(max(M * N * 3, 1 << 20), device="cuda")
-    ops.gemm_dw(dev(dY), dev(X), acc, ws)
+    db0 = rnd(M, seed=15)
+    db = dev(db0.clone())
+    ops.gemm_dw(dev(dY), dev(X), acc, ws, db=db)
     assert_close(acc, acc0 + dY.float().t() @ X.float(), 1e-4, 1e-3 * K ** 0.5 / 30, f"gemm_dw {mnk}")
+    assert_close(db, db0 + dY.float().sum(0), 1e-4, 1e-3 * K ** 0.5 / 30, f"gemm_dw bias grad {mnk}")
     # padded operands (ld > width), as the patch-embed / decoder_pred gradients use
     dYp = torch.zeros(K, M + 8, dtype=dtype); dYp[:, :M] = dY
     acc = dev(acc0.clone())
@@ -180,6 +184,11 @@ def test_layernorm(ops, MD, dtype):
     assert_close(dxlp, xr.grad + dres, 1e-4 if dtype == torch.float32 else 1e-2, 1e-4 if dtype == torch.float32 else 2e-2, "ln dx lp")
     assert_close(dg, gr.grad, 1e-4, 1e-3, "ln dgamma")
     assert_close(db, br.grad, 1e-4, 1e-3, "ln dbeta")
+    # per-block partial rows instead of atomics (what the engine uses): accumulates on top of existing content
+    pw = torch.empty(64 * 2 * D, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dx, dg, db, dres_in=dev(dres), dx_lp=dxlp, partial_ws=pw)
+    assert_close(dg, 2 * gr.grad, 1e-4, 2e-3, "ln dgamma (partials)")
+    assert_close(db, 2 * br.grad, 1e-4, 2e-3, "ln dbeta (partials)")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
