@@ -160,13 +160,14 @@ class Workspace:
         # backward scratch (shared by all layers)
         Mmax_e, Mmax_d = Me, Md
         self.gout = torch.ones(1, **f32)
+        # buffers that the weight-gradient stream reads are ping-ponged so the main chain never waits for it (see Engine._dw)
         self.dres_e = E(Mmax_e, D, **f32)
-        self.dres_e_lp = E(Mmax_e, D, **lp)
+        self.dres_e_lp = [E(Mmax_e, D, **lp), E(Mmax_e, D, **lp)]
         self.dres_d = E(Mmax_d, Dd, **f32)
-        self.dres_d_lp = E(Mmax_d, Dd, **lp)
+        self.dres_d_lp = [E(Mmax_d, Dd, **lp), E(Mmax_d, Dd, **lp)]
         big = max(Me * 4 * D, Md * 4 * Dd)
-        self.t4 = E(big, **lp)      # dpre
-        self.t3 = E(max(Me * 3 * D, Md * 3 * Dd), **lp)  # dqkv
+        self.t4 = [E(big, **lp), E(big, **lp)]      # dpre
+        self.t3 = [E(max(Me * 3 * D, Md * 3 * Dd), **lp) for _ in range(2)]  # dqkv
         self.t1 = E(max(Me * D, Md * Dd), **lp)          # dy / do
         self.dpred_lp = E(Md, Pp, **lp)
         self.demb = E(Md, Dd, **f32)
@@ -199,6 +200,8 @@ class Engine:
         self.ws: Optional[Workspace] = None
         self.lp_fresh = False
         self._saved = None
+        self.side, self.main = None, None
+        self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
 
     # ------------------------------------------------------------------ helpers
     def W(self, name):
@@ -235,13 +238,40 @@ class Engine:
         return max(1, min(want, kt // 4 if kt >= 8 else 1))
 
     def _dw(self, dy, x, name):
-        """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored)."""
+        """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored).
+
+        Weight gradients are leaves of the backward graph, so they run on a second HIP stream: their ~250-workgroup kernels and
+        the slab reduce fill the CUs that the main chain's tails, small GEMMs, LayerNorm and attention kernels leave idle."""
         gw = self.flat.G(name + ".weight")
         gw2 = gw.view(gw.shape[0], -1)
-        tile, kt = (128, 64) if self.T == BF16 else (64, 16)
-        sk = self._splitk(gw2.shape[0], gw2.shape[1], dy.shape[0], tile, kt)
         dyv, xv = dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]]
-        ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, db=self.flat.G(name + ".bias"), st=self.st)
+        if ops._timer is not None:  # per-kernel HIP-event timing (bench.py) measures on the main stream
+            ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, db=self.flat.G(name + ".bias"), st=self.st)
+            return
+        side = self.side
+        ev = self._event()
+        ev.record(self.main)
+        side.wait_event(ev)
+        ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, db=self.flat.G(name + ".bias"), st=side.cuda_stream)
+        done = self._event()
+        done.record(side)
+        self._side_reads[dy.data_ptr()] = done
+
+    def _guard_write(self, buf):
+        """Main stream is about to overwrite `buf`: wait for the weight-gradient kernel that still reads it (if any)."""
+        ev = self._side_reads.pop(buf.data_ptr(), None)
+        if ev is not None:
+            self.main.wait_event(ev)
+
+    def _event(self):
+        if self._ev_i == len(self._events):
+            self._events.append(torch.cuda.Event())
+        self._ev_i += 1
+        return self._events[self._ev_i - 1]
+
+    def _join_side(self):
+        self.main.wait_stream(self.side)
+        self._side_reads.clear()
 
     # ------------------------------------------------------------------ transformer block
     def _block_fwd(self, S, i, pre, M, Dm, H, B2, T):
@@ -257,26 +287,33 @@ class Engine:
         ops.gemm(S["y2"][i], self.W(pre + "mlp.fc1.weight"), S["h"][i], bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=S["pre"][i], st=st)
         ops.gemm(S["h"][i], self.W(pre + "mlp.fc2.weight"), x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st)
 
-    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, dres_lp):
+    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps):
+        """`lps` = the two ping-pong low-precision copies of the residual gradient; on entry and on exit lps[0] is current."""
         P, G, st, ws = self.flat.P, self.flat.G, self.st, self.ws
         stt = S["st"][i]
         lse = S["lse"][i][: B2 * H * T]
-        dpre = ws.t4[: M * 4 * Dm].view(M, 4 * Dm)
-        dqkv = ws.t3[: M * 3 * Dm].view(M, 3 * Dm)
+        self._tog ^= 1
+        dpre = ws.t4[self._tog][: M * 4 * Dm].view(M, 4 * Dm)
+        dqkv = ws.t3[self._tog][: M * 3 * Dm].view(M, 3 * Dm)
         t1 = ws.t1[: M * Dm].view(M, Dm)
-        self._dw(dres_lp, S["h"][i], pre + "mlp.fc2")
-        ops.gemm(dres_lp, self.W(pre + "mlp.fc2.weight"), dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st)
+        cur, nxt = lps
+        self._dw(cur, S["h"][i], pre + "mlp.fc2")
+        self._guard_write(dpre)
+        ops.gemm(cur, self.W(pre + "mlp.fc2.weight"), dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st)
         self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
         ops.gemm(dpre, self.W(pre + "mlp.fc1.weight"), t1, trans_b=True, st=st)
+        self._guard_write(nxt)
         ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, G(pre + "norm2.weight"), G(pre + "norm2.bias"),
-                          dres_in=dres, dx_lp=dres_lp, partial_ws=ws.ln_ws, st=st)
-        self._dw(dres_lp, S["o"][i], pre + "attn.proj")
-        ops.gemm(dres_lp, self.W(pre + "attn.proj.weight"), t1, trans_b=True, st=st)
+                          dres_in=dres, dx_lp=nxt, partial_ws=ws.ln_ws, st=st)
+        self._dw(nxt, S["o"][i], pre + "attn.proj")
+        ops.gemm(nxt, self.W(pre + "attn.proj.weight"), t1, trans_b=True, st=st)
+        self._guard_write(dqkv)
         ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
         self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
         ops.gemm(dqkv, self.W(pre + "attn.qkv.weight"), t1, trans_b=True, st=st)
+        self._guard_write(cur)
         ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, G(pre + "norm1.weight"), G(pre + "norm1.bias"),
-                          dres_in=dres, dx_lp=dres_lp, partial_ws=ws.ln_ws, st=st)
+                          dres_in=dres, dx_lp=cur, partial_ws=ws.ln_ws, st=st)
 
     # ------------------------------------------------------------------ forward
     def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool):
@@ -361,6 +398,11 @@ class Engine:
         self.st = st = ops.stream()
         N, keep = sv["N"], sv["keep"]
         B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
+        self.main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        self._ev_i, self._tog = 0, 0
+        self._side_reads.clear()
         if not accumulate:
             self.flat.g.zero_()
         ws.gout.copy_(gout.reshape(1).to(torch.float32))
@@ -383,7 +425,7 @@ class Engine:
             ops.rows_scatter_add(ws.dpin, ws.demb, L, Td, N * Td + 1, st=st)
         # decoder
         ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d,
-                          G("decoder_norm.weight"), G("decoder_norm.bias"), dx_lp=ws.dres_d_lp, partial_ws=ws.ln_ws, st=st)
+                          G("decoder_norm.weight"), G("decoder_norm.bias"), dx_lp=ws.dres_d_lp[0], partial_ws=ws.ln_ws, st=st)
         for i in reversed(range(c["Nd"])):
             self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp)
         ops.unshuffle_bwd(ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
@@ -392,6 +434,7 @@ class Engine:
         ops.gemm(ws.dz_lp, self.W("decoder_embed.weight"), ws.dres_e, trans_b=True, st=st)
         dp = getattr(self.module, "_dp", None)
         if dp is not None:
+            self._join_side()
             dp.grads_ready(self.flat, "tail")  # decoder + heads are final: their all-reduce overlaps the encoder backward
         latent = ws.enc["x"][c["Ne"]]
         if self.has_le:
@@ -402,12 +445,14 @@ class Engine:
         if self.has_ce:
             ops.ntxent_bwd(ws.zc, ws.inv_norm, ws.E, ws.neg, ws.gout, ws.dpool, N, st=st)
             dpool = ws.dpool
-        ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp, B2, Te, st=st)
+        ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp[0], B2, Te, st=st)
         for i in reversed(range(c["Ne"])):
             self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, ws.dres_e, ws.dres_e_lp)
-            if dp is not None:
+            if dp is not None and dp.wants(("enc", i)):
+                self._join_side()
                 dp.grads_ready(self.flat, ("enc", i))
         ops.embed_assemble_bwd(ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
+        self._join_side()
         ops.gemm_dw(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), ws.dw_ws, db=G("patch_embed.proj.bias"), st=st)
         if dp is not None:
             dp.grads_ready(self.flat, "stem")

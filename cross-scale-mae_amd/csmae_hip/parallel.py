@@ -129,6 +129,10 @@ class DataParallel(torch.nn.Module):
         if name in self._ranges:
             sync.reduce_range(*self._ranges[name])
 
+    def wants(self, name) -> bool:
+        """True if `name` closes a bucket (lets the engine skip joining its weight-gradient stream otherwise)."""
+        return self.require_backward_grad_sync and is_dist() and self._sync is not None and name in self._ranges
+
     def backward_done(self, flat):
         if self._sync is not None:
             self._sync.finish()

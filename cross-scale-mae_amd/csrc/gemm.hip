@@ -158,7 +158,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f4_t (&acc)[FM]
   }
 }
 
-template <bool TA, bool TB, int BM, int BN, int WM, int WN, int GEMM_STAGES>
+template <bool TA, bool TB, int BM, int BN, int WM, int WN, int GEMM_STAGES, bool DB>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * GEMM_BK * 2, B_BYTES = BN * GEMM_BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -233,21 +233,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
     else { int q = (wn >> 4) + j, key = (t >> 2) | ((g & 1) << 2); rb[j] = ((q ^ key) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BN * 2); }
   }
 
-#pragma unroll
-  for (int s = 0; s < GEMM_STAGES - 1; ++s)
-    if (kt_begin + s < kt_end) stage(kt_begin + s);
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    // wait for this wave's pieces of tile kt (tiles kt+1, kt+2 may stay in flight), then meet the other waves
-    if (GEMM_STAGES >= 4 && kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-    else if (GEMM_STAGES >= 3 && kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + GEMM_STAGES - 1 < kt_end && !(p.force_cfg & 64)) stage(kt + GEMM_STAGES - 1);  // refills the stage every wave finished reading before the barrier
-    if (p.force_cfg & 32) continue;
+  // ---- main loop.  Fragments are double-buffered in registers: while the MFMAs of K-tile kt run on one register set, the LDS
+  // reads of K-tile kt+1 (made visible by the barrier at the top of the iteration) land in the other, so neither the barrier
+  // skew nor the ds_read latency sits in front of the matrix pipe.  The stage whose fragments were consumed into registers is
+  // refilled right after the barrier: GEMM_STAGES - 1 K-tiles of buffer_load..lds stay in flight (counted vmcnt, raw s_barrier).
+  auto read_frags = [&](int kt, s8_t (&fa)[FM], s8_t (&fb)[FN]) {
     const char* sa = smem + ((kt - kt_begin) % GEMM_STAGES) * STAGE;
     const char* sb = sa + A_BYTES;
-    s8_t fa[FM], fb[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       if (!TA) fa[i] = *reinterpret_cast<const s8_t*>(sa + ra[i]);
@@ -266,6 +258,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
         fb[j] = s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     }
+  };
+  auto mma = [&](const s8_t (&fa)[FM], const s8_t (&fb)[FN]) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -275,6 +269,50 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(G
 #pragma unroll
       for (int i = 0; i < FM; ++i)
         accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, ones), __builtin_bit_cast(bf8_t, fa[i]), accb[i], 0, 0, 0);
+    }
+  };
+  // make K-tile kt visible: wait for this wave's pieces of it (`later` younger tiles may stay in flight), then meet the other waves
+  auto arrive = [&](int kt, int issued_last) {
+    const int later = issued_last - kt;
+    if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our own earlier fragment reads have left the stage that is about to be refilled
+    __builtin_amdgcn_s_barrier();
+  };
+  const int last = kt_end - 1;
+  if (DB) {
+    int issued = min(kt_begin + GEMM_STAGES - 1, last);
+    for (int kt = kt_begin; kt <= issued; ++kt) stage(kt);
+    s8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+    arrive(kt_begin, issued);
+    read_frags(kt_begin, fa0, fb0);
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      if (kt + 1 < kt_end) {
+        arrive(kt + 1, issued);
+        if (issued < last) stage(++issued);  // into the stage of tile kt: its fragments are in fa0/fb0
+        read_frags(kt + 1, fa1, fb1);
+      }
+      mma(fa0, fb0);
+      if (kt + 1 >= kt_end) break;
+      if (kt + 2 < kt_end) {
+        arrive(kt + 2, issued);
+        if (issued < last) stage(++issued);
+        read_frags(kt + 2, fa0, fb0);
+      }
+      mma(fa1, fb1);
+    }
+  } else {
+    // single register set (the 128x64 wave tile leaves no room for a second one): fragments are read after the barrier
+    int issued = min(kt_begin + GEMM_STAGES - 2, last);
+    for (int kt = kt_begin; kt <= issued; ++kt) stage(kt);
+    s8_t fa0[FM], fb0[FN];
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      arrive(kt, issued);
+      if (issued < last) stage(++issued);  // into the stage read during iteration kt-1 (every wave is past it: barrier above)
+      read_frags(kt, fa0, fb0);
+      mma(fa0, fb0);
     }
   }
   if (do_cs && g == 0) {
@@ -406,7 +444,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     // fewer tiles than CUs (N = 768 outputs: 150 tiles) because it halves the bytes staged per flop; 256x128 never won.
     int cfg = (M >= 256 && N >= 256) ? 2 : 0;  // 0: 128x128 (4 waves, 2 blocks/CU)  2: 256x256 (8 waves, 1 block/CU)
     int stg = 4;
-    if (p.force_cfg >= 0) cfg = (p.force_cfg & 3) == 2 ? 2 : 0; else p.force_cfg = 0;
+    if (p.force_cfg >= 0) cfg = p.force_cfg & 3; else p.force_cfg = 0;
     (void)stg;
     const int bm = cfg == 0 ? 128 : 256, bn = cfg == 2 ? 256 : 128;
     p.tiles_m = cdiv(M, bm); p.tiles_n = cdiv(N, bn);
@@ -414,8 +452,9 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     p.splitk = cdiv(p.ktiles, p.ktiles_per_split);
     dim3 grid(p.tiles_m * p.tiles_n * p.splitk);
 #define LAUNCH_CFG(TA_, TB_)                                                                                              \
-    if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4>), grid, dim3(512), 0, st, p);       \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4>), grid, dim3(256), 0, st, p);
+    if (cfg == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 128, 64, 64, 4, true>), grid, dim3(512), 0, st, p);         \
+    else if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, false>), grid, dim3(512), 0, st, p);  \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4, false>), grid, dim3(256), 0, st, p);
     if (!transA && !transB) { LAUNCH_CFG(false, false) }
     else if (!transA && transB) { LAUNCH_CFG(false, true) }
     else if (transA && transB) { LAUNCH_CFG(true, true) }
