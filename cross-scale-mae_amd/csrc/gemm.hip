@@ -109,7 +109,7 @@ template <typename TC, int EPI, int FM, int FN, int WM, int EROWS, int ESTR, int
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
   constexpr int NPASS = EROWS / RPP, NPART = WM / EROWS;
   constexpr bool NEEDS_LOAD = EPI == EPI_RESID || EPI == EPI_DGELU;
-  constexpr bool PRELOAD_ALL = (WM <= 64);  // all residual/aux rows of the wave tile fit in registers
+  constexpr bool PRELOAD_ALL = false;  // (WM <= 64) would fit all residual/aux rows in registers but costs the occupancy of the 2-blocks/CU tile
   const int col = (lane % LPR) * 4, rsub = lane / LPR;
   const int gn = nbase + col;
   const bool colok = gn < p.N;
@@ -158,8 +158,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f4_t (&acc)[FM]
   }
 }
 
-template <bool TA, bool TB, int BM, int BN, int WM, int WN, int GEMM_STAGES, bool DB>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(GemmArgs p) {
+template <bool TA, bool TB, int BM, int BN, int WM, int WN, int GEMM_STAGES, bool DB, int MINW = 1>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, FM = WM / 16, FN = WN / 16;
   constexpr int A_BYTES = BM * GEMM_BK * 2, B_BYTES = BN * GEMM_BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024, PPW = (PA + PB) / NW;
@@ -452,7 +452,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     p.splitk = cdiv(p.ktiles, p.ktiles_per_split);
     dim3 grid(p.tiles_m * p.tiles_n * p.splitk);
 #define LAUNCH_CFG(TA_, TB_)                                                                                              \
-    if (cfg == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 128, 64, 64, 4, true>), grid, dim3(512), 0, st, p);         \
+    if (cfg == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 128, 64, 64, 3, false, 4>), grid, dim3(512), 0, st, p);     \
     else if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, false>), grid, dim3(512), 0, st, p);  \
     else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4, false>), grid, dim3(256), 0, st, p);
     if (!transA && !transB) { LAUNCH_CFG(false, false) }

@@ -181,7 +181,7 @@ extern "C" int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int 
 // ------------------------------------------------------------------------------------------ BatchNorm(token axis)+ReLU
 // u is [N*L, Hp]; channel = token position l; statistics over the N*Hp values {u[n*L + l, :]} (models_mae/MLP.py:7).
 template <typename T>
-__global__ __launch_bounds__(256) void bnrelu_fwd_kernel(int N, int L, int Hp, const T* __restrict__ u, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void bnrelu_fwd_kernel(int N, int L, int Hp, const T* __restrict__ u, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, float momentum, T* __restrict__ r,
                                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
                                                          float* __restrict__ run_var, long long* __restrict__ nbt, int training) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(int N, int L, int Hp, c
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bnrelu_bwd_kernel(int N, int L, int Hp, const T* __restrict__ u, const T* __restrict__ dr,
+__global__ __launch_bounds__(1024) void bnrelu_bwd_kernel(int N, int L, int Hp, const T* __restrict__ u, const T* __restrict__ dr,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ du,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -267,8 +267,8 @@ extern "C" int csmae_bnrelu_fwd(int dtype, int N, int L, int Hp, const void* u, 
   CSMAE_REQUIRE(!training || (long long)N * Hp > 1, "csmae_bnrelu_fwd: need more than one value per channel (torch raises the same)");
   CSMAE_REQUIRE(training || (running_mean && running_var), "csmae_bnrelu_fwd: eval mode needs running statistics");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t>), dim3(L), dim3(256), 0, st, N, L, Hp, (const bf16_t*)u, gamma, beta, eps, momentum, (bf16_t*)r, mean, rstd, running_mean, running_var, num_batches_tracked, training);
-  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_fwd_kernel<float>), dim3(L), dim3(256), 0, st, N, L, Hp, (const float*)u, gamma, beta, eps, momentum, (float*)r, mean, rstd, running_mean, running_var, num_batches_tracked, training);
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t>), dim3(L), dim3(1024), 0, st, N, L, Hp, (const bf16_t*)u, gamma, beta, eps, momentum, (bf16_t*)r, mean, rstd, running_mean, running_var, num_batches_tracked, training);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_fwd_kernel<float>), dim3(L), dim3(1024), 0, st, N, L, Hp, (const float*)u, gamma, beta, eps, momentum, (float*)r, mean, rstd, running_mean, running_var, num_batches_tracked, training);
   else { csmae_set_error("csmae_bnrelu_fwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_bnrelu_fwd");
 }
@@ -277,8 +277,8 @@ extern "C" int csmae_bnrelu_bwd(int dtype, int N, int L, int Hp, const void* u, 
                                 const float* mean, const float* rstd, void* du, float* dgamma, float* dbeta, void* stream) {
   CSMAE_REQUIRE(N > 0 && L > 0 && Hp > 0 && Hp % 4 == 0, "csmae_bnrelu_bwd: bad geometry N=%d L=%d Hp=%d", N, L, Hp);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_bwd_kernel<bf16_t>), dim3(L), dim3(256), 0, st, N, L, Hp, (const bf16_t*)u, (const bf16_t*)dr, gamma, beta, mean, rstd, (bf16_t*)du, dgamma, dbeta);
-  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_bwd_kernel<float>), dim3(L), dim3(256), 0, st, N, L, Hp, (const float*)u, (const float*)dr, gamma, beta, mean, rstd, (float*)du, dgamma, dbeta);
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((bnrelu_bwd_kernel<bf16_t>), dim3(L), dim3(1024), 0, st, N, L, Hp, (const bf16_t*)u, (const bf16_t*)dr, gamma, beta, mean, rstd, (bf16_t*)du, dgamma, dbeta);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((bnrelu_bwd_kernel<float>), dim3(L), dim3(1024), 0, st, N, L, Hp, (const float*)u, (const float*)dr, gamma, beta, mean, rstd, (float*)du, dgamma, dbeta);
   else { csmae_set_error("csmae_bnrelu_bwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_bnrelu_bwd");
 }
