@@ -40,7 +40,7 @@ __device__ __forceinline__ s8_t frag_cols_tr(const char* img, int r0, int c0, in
   const char* p = img + (r0 + 4 * g + (t >> 2)) * AttnLds<HD>::STRIDE + (c0 + (t & 3) * 4) * 2;
   s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, p));
   s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, p + 16 * AttnLds<HD>::STRIDE));
-  return s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return join_s4(lo, hi);
 }
 __device__ __forceinline__ s8_t pack_pair(f4_t a, f4_t b) {
   unsigned u0 = pack2bf(a[0], a[1]), u1 = pack2bf(a[2], a[3]), u2 = pack2bf(b[0], b[1]), u3 = pack2bf(b[2], b[3]);
@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
   const float c2 = scale * LOG2E;
   const int nqb = (T + 15) >> 4;
+  constexpr int FIRST_PARTIAL = NKF <= 2 ? 0 : (NKF <= 6 ? NKF - 2 : (NKF == 14 ? 6 : 14));  // floor(T_min / 16) of the bucket dispatching to this NKF
+  const int kthr = T - 4 * g;  // key f*16 + 4g + r is padding  <=>  f*16 + r >= kthr
   for (int qb = w; qb < nqb; qb += 4) {
     const int q = qb * 16 + t;
     s8_t fq[KS];
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) a = MFMA16(frag_rows<HD>(Ks, f * 16, ks, t, g), fq[ks], a);
       a *= c2;
-      if (f * 16 + 16 > T) {  // only the trailing fragment(s) hold padded keys (wave-uniform test)
+      if (f >= FIRST_PARTIAL) {  // only fragments that can hold padded keys for this (T bucket) are masked
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (f * 16 + 4 * g + r >= T) a[r] = -INFINITY;
+        for (int r = 0; r < 4; ++r) a[r] = (f * 16 + r >= kthr) ? -INFINITY : a[r];
       }
       m = fmaxf(fmaxf(m, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
       s[f] = a;
@@ -179,10 +181,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
         float p = __builtin_amdgcn_exp2f(a[r] * c2 - my_l2);
         ds[r] = p * (dp[r] - my_dl) * scale;
       }
-      if (f * 16 + 16 > T) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (f * 16 + 4 * g + r >= T) ds[r] = 0.f;
-      }
+      // no key masking needed here: padded K rows are zero, so whatever dS holds for a padded key adds 0 to dQ
       if (f & 1) fds[f >> 1] = pack_pair(prev, ds); else prev = ds;
     }
 #pragma unroll

@@ -21,6 +21,13 @@ typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
+// two transposed 4x16-bit reads -> one 8x16-bit MFMA operand by register naming only (element-wise vector construction made
+// hipcc emit v_perm/v_or shuffles per fragment)
+__device__ __forceinline__ s8_t join_s4(s4_t lo, s4_t hi) {
+  const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(s8_t, make_uint4(l.x, l.y, h.x, h.y));
+}
+
 // ---- error plumbing (thread-local message; see include/csmae.h csmae_last_error)
 void csmae_set_error(const char* fmt, ...);
 int csmae_check_launch(const char* what);

@@ -246,7 +246,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
       else {
         s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + ra[i]));
         s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + ra[i] + 4 * BM * 2));
-        fa[i] = s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fa[i] = join_s4(lo, hi);
       }
     }
 #pragma unroll
@@ -255,7 +255,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
       else {
         s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j]));
         s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j] + 4 * BN * 2));
-        fb[j] = s8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fb[j] = join_s4(lo, hi);
       }
     }
   };
