@@ -83,6 +83,9 @@ def cpu_baseline(seconds_budget=30.0):
                        f"{threads} torch threads of {os.cpu_count()} host cores")
 
 
+SETTLE_STEPS = 10
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,7 +120,12 @@ def main():
         opt.step()
         return loss
 
-    log(f"model built; warm-up {a.warmup} steps")
+    # Initialisation, not measurement: the first ~8 steps of a process carry one-off costs (allocator growth, HIP signal / kernarg
+    # pools, clock ramp) that showed up as a 70-100 ms stall somewhere in steps 5..10 when the queue runs unsynchronised.
+    for _ in range(SETTLE_STEPS):
+        step()
+    torch.cuda.synchronize()
+    log(f"model built and settled ({SETTLE_STEPS} steps); warm-up {a.warmup} steps")
     for _ in range(a.warmup):
         loss = step()
     torch.cuda.synchronize()

@@ -17,6 +17,7 @@
 // ends with 4 consecutive output columns -> 8/16-byte epilogue accesses.
 // fp32 path: exact-fp32 FMA tile kernel used for the 1e-4 parity mode (not the throughput path).
 #include "common.h"
+#include <type_traits>
 
 #define EPI_NONE 0    // C = acc + bias
 #define EPI_GELU 1    // x = acc + bias ; C = gelu(x) ; aux = gelu'(x)
@@ -282,37 +283,53 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
     __builtin_amdgcn_s_barrier();
   };
   const int last = kt_end - 1;
+  const int dbg = p.force_cfg;  // tuning aid (csmae_gemm_force_tile): 16 main loop only, 32 no DMA, 64 no MFMA, 128 no fragment reads
   if (DB) {
-    int issued = min(kt_begin + GEMM_STAGES - 1, last);
+    // Ping-pong schedule.  The two waves that share a SIMD (w and w + NW/2: a workgroup's waves are dealt to the SIMDs cyclically)
+    // run half an iteration apart: while one group issues its DMA pieces and pulls fragments out of LDS ("R" phase), the other
+    // group owns the matrix pipe ("M" phase).  Two barriers per K-tile keep the groups in that lock step; group 1 enters the
+    // loop one barrier late and leaves it one barrier early, so every wave executes the same number of s_barriers.
+    //   interval 2k  : group 0 R(k)   | group 1 M(k-1)          interval 2k+1 : group 0 M(k) | group 1 R(k)
+    // R(k) = refill the ring slot of tile k-1 (read by both groups before interval 2k), read tile k, then retire this wave's
+    // own pieces of tile k+1 so that they are visible to the other group one barrier before anybody reads them.
+    const int grp = w / (NW / 2);
+    int issued = min(kt_begin + GEMM_STAGES - 2, last);
     for (int kt = kt_begin; kt <= issued; ++kt) stage(kt);
-    s8_t fa0[FM], fb0[FN], fa1[FM], fb1[FN];
-    arrive(kt_begin, issued);
-    read_frags(kt_begin, fa0, fb0);
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
-      if (kt + 1 < kt_end) {
-        arrive(kt + 1, issued);
-        if (issued < last) stage(++issued);  // into the stage of tile kt: its fragments are in fa0/fb0
-        read_frags(kt + 1, fa1, fb1);
-      }
-      mma(fa0, fb0);
-      if (kt + 1 >= kt_end) break;
-      if (kt + 2 < kt_end) {
-        arrive(kt + 2, issued);
-        if (issued < last) stage(++issued);
-        read_frags(kt + 2, fa0, fb0);
-      }
-      mma(fa1, fb1);
+    auto retire = [&](int later) {
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    retire(issued - kt_begin);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    s8_t fa0[FM] = {}, fb0[FN] = {};
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (issued < last) { ++issued; if (!(dbg & 32)) stage(issued); }
+      if (!(dbg & 128)) read_frags(kt, fa0, fb0);
+      if (kt < last) retire(issued - (kt + 1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (!(dbg & 64)) mma(fa0, fb0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(grp == 1 && kt == last)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     // single register set (the 128x64 wave tile leaves no room for a second one): fragments are read after the barrier
     int issued = min(kt_begin + GEMM_STAGES - 2, last);
     for (int kt = kt_begin; kt <= issued; ++kt) stage(kt);
-    s8_t fa0[FM], fb0[FN];
+    s8_t fa0[FM] = {}, fb0[FN] = {};
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       arrive(kt, issued);
-      if (issued < last) stage(++issued);  // into the stage read during iteration kt-1 (every wave is past it: barrier above)
-      read_frags(kt, fa0, fb0);
-      mma(fa0, fb0);
+      if (issued < last) { ++issued; if (!(dbg & 32)) stage(issued); }  // into the stage read during iteration kt-1 (every wave is past it: barrier above)
+      if (!(dbg & 128)) read_frags(kt, fa0, fb0);
+      if (!(dbg & 64)) mma(fa0, fb0);
     }
   }
   if (do_cs && g == 0) {
@@ -339,7 +356,180 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
   constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR;
   constexpr int EROWS = (NW * 32 * ESTR * 4 <= GEMM_STAGES * STAGE) ? 32 : 16;  // strip height that fits the staging ring
   static_assert(NW * EROWS * ESTR * 4 <= GEMM_STAGES * STAGE, "epilogue strip must fit the staging ring");
-  __syncthreads();
+  if (!DB) __syncthreads();  // (ping-pong: every fragment read is already behind the loop's last barrier)
+  float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
+#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+  if (p.c_dtype == CSMAE_BF16) {
+    if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
+    else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID); else EPI_CALL(bf16_t, EPI_NONE);
+  } else {
+    if (p.epi == EPI_GELU) EPI_CALL(float, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(float, EPI_DGELU);
+    else if (p.epi == EPI_RESID) EPI_CALL(float, EPI_RESID); else EPI_CALL(float, EPI_NONE);
+  }
+#undef EPI_CALL
+}
+
+// ------------------------------------------------------------------------------------ bf16 MFMA, 64-wide K steps
+// Measured with tools/dma_probe.hip: `buffer_load ... lds` of 64-B row segments (a 32-wide K tile of a K-contiguous bf16
+// operand = half a cache line per row) moves 28 B/clk/CU out of a warm L2, 128-B segments move 56 B/clk/CU.  At 256x256x32 the
+// first figure is 1175 clk per K-tile against 1088 clk of MFMA work: the forward / dX kernels were bound by staging.  This
+// variant therefore steps K by 64 so every K-contiguous row is fetched as one full line.  LDS is a ring of five 32-KiB units
+// (all 160 KiB), one unit = one operand's [256 x 64] image; a K step consumes units (2j, 2j+1) while 2j+2 .. 2j+4 are in flight.
+//   K-contiguous image: [256 rows][64 k], 128-B rows, 16-B chunk swizzle c ^ (row & 7) (conflict-free ds_read_b128)
+//   K-strided image   : two [32 k][256] images of the 32-wide kernel back to back (ds_read_b64_tr_b16)
+template <bool TB>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, WM = 128, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
+  constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;
+  __shared__ __attribute__((aligned(16))) char smem[NUNIT * UNIT];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = lane & 15, g = lane >> 4;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, tiles);  // (no split-K: the weight-gradient products use the K-strided kernel)
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kt_begin = 0, kt_end = p.ktiles, Kdim = p.K;
+
+  auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+  auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  const unsigned kstepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
+
+  unsigned aoff[PPU], boff[PPU]; int ak[PPU], bk[PPU]; bool aok[PPU], bok[PPU];
+#pragma unroll
+  for (int q = 0; q < PPU; ++q) {
+    const int pi = w * PPU + q;
+    {
+      const int row = pi * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      const long long gr = m0 + row;
+      aok[q] = gr < p.M; ak[q] = c * 8; aoff[q] = (unsigned)((gr * p.lda + c * 8) * 2);
+    }
+    if (!TB) {
+      const int row = pi * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      const long long gr = n0 + row;
+      bok[q] = gr < p.N; bk[q] = c * 8; boff[q] = (unsigned)((gr * p.ldb + c * 8) * 2);
+    } else {
+      PieceDesc<true, BN> d; d.init(pi, lane, n0, p.N, p.ldb); boff[q] = d.off; bk[q] = d.kidx; bok[q] = d.ok;
+    }
+  }
+  const int dbg = p.force_cfg;  // tuning aid (csmae_gemm_force_tile): 16 = main loop only
+  auto dma_a = [&](int u, int q) {  // piece q of this wave's share of unit u, an A image (units count from the first K step)
+    const int j = u >> 1;
+    const unsigned o = (aok[q] && j * 64 + ak[q] < Kdim) ? aoff[q] + (unsigned)j * 128u : OOB_OFF;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, smem + (u % NUNIT) * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
+  };
+  auto dma_b = [&](int u, int q) {
+    const int j = u >> 1;
+    const unsigned o = (bok[q] && j * 64 + bk[q] < Kdim) ? boff[q] + (unsigned)j * kstepB : OOB_OFF;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, smem + (u % NUNIT) * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
+  };
+
+  f4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const int wm = (w / NWN) * WM, wn = (w % NWN) * WN;
+  // fragment offsets (K half 0); the other half is `^ 64` for the swizzled K-contiguous image, `+ 32 rows` for the K-strided one
+  const int ra0 = (wm + t) * 128 + ((g ^ (t & 7)) << 4);
+  int rb[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    if (!TB) rb[j] = (wn + j * 16 + t) * 128 + ((g ^ (t & 7)) << 4);
+    else { int q = (wn >> 4) + j, key = (t >> 2) | ((g & 1) << 2); rb[j] = ((q ^ key) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BN * 2); }
+  }
+  auto read_a = [&](int u, int h, int i, s8_t& fa) {
+    fa = *reinterpret_cast<const s8_t*>(smem + (u % NUNIT) * UNIT + ((ra0 + i * 2048) ^ (h << 6)));
+  };
+  auto read_b = [&](int u, int h, s8_t (&fb)[FN]) {
+    const char* sb = smem + (u % NUNIT) * UNIT;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      if (!TB) fb[j] = *reinterpret_cast<const s8_t*>(sb + (rb[j] ^ (h << 6)));
+      else {
+        s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j] + h * (32 * BN * 2)));
+        s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j] + h * (32 * BN * 2) + 4 * BN * 2));
+        fb[j] = join_s4(lo, hi);
+      }
+    }
+  };
+  auto mma_row = [&](int i, const s8_t& fa, const s8_t (&fb)[FN]) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa), acc[i][j], 0, 0, 0);
+  };
+  // ---- software-pipelined main loop.  A K step is 16 "rows" of 4 MFMAs (8 A fragments x 2 K halves).  The LDS reads of the next
+  // half and the DMA pieces of the units freed by the step's barrier are issued one per row, between the MFMAs, so that their
+  // issue cost (~100 clk per `buffer_load .. lds`) and latency run under the matrix pipe instead of in front of it: an A fragment
+  // is re-read in place as soon as its row has been issued, only the B fragments are double-buffered (64 fragment VGPRs in all).
+  // The one barrier of the step sits after row 1 of the second half: at that point every wave has all fragments of the step in
+  // registers (lgkmcnt(0)), so its two units can be refilled, and has retired its own pieces of the next step's units.
+  // The body is straight-line code (a branch would make the compiler drain lgkmcnt at every block head), so the last three
+  // steps, which have fewer or no units left to fetch and nothing to prefetch, are separate instantiations (MODE 1..3).
+  const int nsteps = kt_end - kt_begin, U = 2 * nsteps;
+  const int issued0 = min(NUNIT - 1, U - 1);
+#pragma unroll
+  for (int u = 0; u < NUNIT; ++u)
+    if (u <= issued0) {
+#pragma unroll
+      for (int q = 0; q < PPU; ++q) { if (u & 1) dma_b(u, q); else dma_a(u, q); }
+    }
+  if (issued0 >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPU) : "memory");
+  else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPU) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  s8_t fa[FM], fb0[FN], fb1[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) read_a(0, 0, i, fa[i]);
+  read_b(1, 0, fb0);
+  // MODE 0: fetch units 2j+5 (B) and 2j+6 (A), prefetch the next step   1: fetch 2j+5 only   2: nothing left to fetch   3: last step
+  auto step = [&](int j, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool more = MODE < 3;
+    const int u0 = 2 * j;
+    read_b(u0 + 1, 1, fb1);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      mma_row(i, fa[i], fb0);
+      read_a(u0, 1, i, fa[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma_row(0, fa[0], fb1);
+    mma_row(1, fa[1], fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPU) : "memory");  // own pieces of units 2j+2, 2j+3 (2j+4 may stay in flight)
+    else if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { read_a(u0 + 2, 0, 0, fa[0]); read_a(u0 + 2, 0, 1, fa[1]); read_b(u0 + 3, 0, fb0); }
+    if (MODE <= 1) { dma_b(u0 + 5, 0); dma_b(u0 + 5, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 2; i < FM; ++i) {
+      mma_row(i, fa[i], fb1);
+      if (more) read_a(u0 + 2, 0, i, fa[i]);
+      if (i < 4) { if (MODE <= 1) dma_b(u0 + 5, i); }
+      else { if (MODE == 0) dma_a(u0 + 6, i - 4); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int j = 0;
+  for (; j < nsteps - 3; ++j) step(j, std::integral_constant<int, 0>{});
+  if (nsteps >= 3) step(j++, std::integral_constant<int, 1>{});
+  if (nsteps >= 2) step(j++, std::integral_constant<int, 2>{});
+  step(j, std::integral_constant<int, 3>{});
+  if ((dbg & 16) && acc[0][0][0] != 123456.0f) return;  // tuning aid: main loop only
+  if (p.epi == EPI_ATOMIC) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        epi_dispatch(p, m0 + wm + i * 16 + t, n0 + wn + j * 16 + 4 * g, acc[i][j]);
+    return;
+  }
+  constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
+  static_assert(NW * EROWS * ESTR * 4 <= NUNIT * UNIT, "epilogue strip must fit the staging ring");
+  // (no barrier: nothing has read or written the ring since the last step's barrier)
   float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
 #define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g)
   if (p.c_dtype == CSMAE_BF16) {
@@ -442,11 +632,14 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     // tile choice: as large as keeps >= ~1.5 rounds of the 256 CUs busy (bytes staged per flop ~ 1/BM + 1/BN)
     // tile choice (measured on the step's shapes, tools/gemm_bench.py): 256x256 wins whenever it fits, also when it leaves
     // fewer tiles than CUs (N = 768 outputs: 150 tiles) because it halves the bytes staged per flop; 256x128 never won.
-    int cfg = (M >= 256 && N >= 256) ? 2 : 0;  // 0: 128x128 (4 waves, 2 blocks/CU)  2: 256x256 (8 waves, 1 block/CU)
+    // 0: 128x128x32 (4 waves, 2 blocks/CU)   2: 256x256x32 (8 waves, 1 block/CU)   4: 256x256x64 software-pipelined (K-contiguous A)
+    int cfg = (M >= 256 && N >= 256) ? ((!transA && splitk == 1) ? 4 : 2) : 0;
     int stg = 4;
-    if (p.force_cfg >= 0) cfg = p.force_cfg & 3; else p.force_cfg = 0;
+    if (p.force_cfg >= 0) cfg = p.force_cfg & 7; else p.force_cfg = 0;
+    if (cfg == 4 && (transA || splitk != 1)) cfg = 2;  // the 64-wide-K kernel exists for K-contiguous A, unsplit K only
+    if (cfg == 4) p.ktiles = cdiv(K, 64);
     (void)stg;
-    const int bm = cfg == 0 ? 128 : 256, bn = cfg == 2 ? 256 : 128;
+    const int bm = cfg == 0 ? 128 : 256, bn = cfg >= 2 ? 256 : 128;
     p.tiles_m = cdiv(M, bm); p.tiles_n = cdiv(N, bn);
     p.ktiles_per_split = cdiv(p.ktiles, splitk);
     p.splitk = cdiv(p.ktiles, p.ktiles_per_split);
@@ -454,8 +647,11 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
 #define LAUNCH_CFG(TA_, TB_)                                                                                              \
     if (cfg == 1) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 128, 64, 64, 3, false, 4>), grid, dim3(512), 0, st, p);     \
     else if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, false>), grid, dim3(512), 0, st, p);  \
+    else if (cfg == 3) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, true>), grid, dim3(512), 0, st, p);   \
     else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4, false>), grid, dim3(256), 0, st, p);
-    if (!transA && !transB) { LAUNCH_CFG(false, false) }
+    if (cfg == 4 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false>), grid, dim3(512), 0, st, p);
+    else if (cfg == 4) hipLaunchKernelGGL((gemm_bf16_k64_kernel<true>), grid, dim3(512), 0, st, p);
+    else if (!transA && !transB) { LAUNCH_CFG(false, false) }
     else if (!transA && transB) { LAUNCH_CFG(false, true) }
     else if (transA && transB) { LAUNCH_CFG(true, true) }
     else { LAUNCH_CFG(true, false) }

@@ -43,11 +43,12 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--atomic", action="store_true", help="weight gradients through the atomic split-K epilogue instead of slabs")
-    ap.add_argument("--cfg", type=int, default=-1, help="force block tile: 0=128x128 1=256x128 2=256x256")
+    ap.add_argument("--cfg", type=int, default=-1, help="force block tile: 0=128x128 1=256x128 2=256x256 3=256x256 ping-pong")
+    ap.add_argument("--dbg", type=int, default=0, help="ablation bits: 16 main loop only, 32 no DMA, 64 no MFMA, 128 no fragment reads")
     a = ap.parse_args()
     from csmae_hip.engine import Engine
     import csmae_hip
-    csmae_hip.load().csmae_gemm_force_tile(a.cfg)
+    csmae_hip.load().csmae_gemm_force_tile(a.cfg | a.dbg if a.cfg >= 0 else a.cfg)
     dev = "cuda"
     tot_ms = tot_fl = 0.0
     for name, lay, M, N, K, epi, odt in CASES:
