@@ -17,6 +17,7 @@
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef short s4_t __attribute__((ext_vector_type(4)));
 typedef short s8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))

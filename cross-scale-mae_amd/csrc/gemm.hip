@@ -107,7 +107,7 @@ struct PieceDesc {
 // epilogue interleaved "load, add, store" per fragment and spent 45 % of the GEMM time in those waits.  So every global load of
 // a phase is issued before the phase's first store, and the stores then go out back to back.
 template <typename TC, int EPI, int FM, int FN, int WM, int EROWS, int ESTR, int LPR, int RPP>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
   constexpr int NPASS = EROWS / RPP, NPART = WM / EROWS;
   constexpr bool NEEDS_LOAD = EPI == EPI_RESID || EPI == EPI_DGELU;
   constexpr bool PRELOAD_ALL = false;  // (WM <= 64) would fit all residual/aux rows in registers but costs the occupancy of the 2-blocks/CU tile
@@ -153,7 +153,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, f4_t (&acc)[FM]
       if (EPI == EPI_DGELU) o = v * ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
       if (colok && gm < p.M) {
         if (EPI == EPI_GELU) st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)gm * p.ldaux + gn, v);
-        st4<TC>(reinterpret_cast<TC*>(p.C) + (long long)gm * p.ldc + gn, o);
+        st4<TC>(reinterpret_cast<TC*>(Cptr) + (long long)gm * p.ldc + gn, o);
       }
     }
   }
@@ -357,8 +357,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
   constexpr int EROWS = (NW * 32 * ESTR * 4 <= GEMM_STAGES * STAGE) ? 32 : 16;  // strip height that fits the staging ring
   static_assert(NW * EROWS * ESTR * 4 <= GEMM_STAGES * STAGE, "epilogue strip must fit the staging ring");
   if (!DB) __syncthreads();  // (ping-pong: every fragment read is already behind the loop's last barrier)
+  void* Cptr = p.C;
   float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
-#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
   if (p.c_dtype == CSMAE_BF16) {
     if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
     else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID); else EPI_CALL(bf16_t, EPI_NONE);
@@ -377,7 +378,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
 // (all 160 KiB), one unit = one operand's [256 x 64] image; a K step consumes units (2j, 2j+1) while 2j+2 .. 2j+4 are in flight.
 //   K-contiguous image: [256 rows][64 k], 128-B rows, 16-B chunk swizzle c ^ (row & 7) (conflict-free ds_read_b128)
 //   K-strided image   : two [32 k][256] images of the 32-wide kernel back to back (ds_read_b64_tr_b16)
-template <bool TB>
+template <bool TA, bool TB>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
   constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;
@@ -385,42 +386,51 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = lane & 15, g = lane >> 4;
   const int tiles = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, tiles);  // (no split-K: the weight-gradient products use the K-strided kernel)
+  const int wg = xcd_remap(blockIdx.x, tiles * p.splitk);
+  const int split = wg / tiles, tile = wg - split * tiles;
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_begin = 0, kt_end = p.ktiles, Kdim = p.K;
+  const int kt_begin = split * p.ktiles_per_split;
+  const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles), Kdim = p.K;
+  if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
+  void* Cptr = p.epi == EPI_SPLIT ? static_cast<void*>(reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride) : p.C;
 
   auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
   auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  const unsigned kstepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
   const unsigned kstepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
 
-  unsigned aoff[PPU], boff[PPU]; int ak[PPU], bk[PPU]; bool aok[PPU], bok[PPU];
-#pragma unroll
-  for (int q = 0; q < PPU; ++q) {
-    const int pi = w * PPU + q;
-    {
-      const int row = pi * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
-      const long long gr = m0 + row;
-      aok[q] = gr < p.M; ak[q] = c * 8; aoff[q] = (unsigned)((gr * p.lda + c * 8) * 2);
-    }
-    if (!TB) {
-      const int row = pi * 8 + (lane >> 3), c = (lane & 7) ^ (row & 7);
-      const long long gr = n0 + row;
-      bok[q] = gr < p.N; bk[q] = c * 8; boff[q] = (unsigned)((gr * p.ldb + c * 8) * 2);
-    } else {
-      PieceDesc<true, BN> d; d.init(pi, lane, n0, p.N, p.ldb); boff[q] = d.off; bk[q] = d.kidx; bok[q] = d.ok;
-    }
+  // DMA descriptors.  Every piece of a wave has the same lane pattern, so the per-lane state is two byte offsets per operand
+  // (even / odd piece: they differ only in the K-strided image's swizzle); the piece's rows and the K step are uniform adds.
+  //   K-contiguous image: piece = 8 rows x 128 B : lane -> row (lane >> 3), physical 16-B chunk (lane & 7), logical chunk ^ (row & 7)
+  //   K-strided image   : piece = 2 k-rows x 512 B: k-row = 8w + 2q + (lane >> 5), 32-B granule swizzled by tr_key(k-row)
+  const int l3 = lane >> 3, l5 = lane >> 5, s16 = lane & 31;
+  const int kc = ((lane & 7) ^ l3) * 8;
+  auto tr_ch = [&](int qodd) { const int key = l5 | (qodd << 1) | ((w & 1) << 2); return (((s16 >> 1) ^ key) << 1) | (s16 & 1); };
+  unsigned avo[2], bvo[2];
+  if (!TA) avo[0] = avo[1] = (unsigned)(((long long)(m0 + w * 32 + l3) * p.lda + kc) * 2);
+  else {
+    avo[0] = (unsigned)(((long long)(w * 8 + l5) * p.lda + m0 + tr_ch(0) * 8) * 2);
+    avo[1] = (unsigned)(((long long)(w * 8 + l5) * p.lda + m0 + tr_ch(1) * 8) * 2);
   }
+  if (!TB) bvo[0] = bvo[1] = (unsigned)(((long long)(n0 + w * 32 + l3) * p.ldb + kc) * 2);
+  else {
+    bvo[0] = (unsigned)(((long long)(w * 8 + l5) * p.ldb + n0 + tr_ch(0) * 8) * 2);
+    bvo[1] = (unsigned)(((long long)(w * 8 + l5) * p.ldb + n0 + tr_ch(1) * 8) * 2);
+  }
+  const unsigned aqs = (unsigned)((TA ? 2 : 8) * p.lda * 2), bqs = (unsigned)((TB ? 2 : 8) * p.ldb * 2);  // advance per piece
+  const int arow = m0 + w * 32 + l3, brow = n0 + w * 32 + l3, krow = w * 8 + l5;
   const int dbg = p.force_cfg;  // tuning aid (csmae_gemm_force_tile): 16 = main loop only
-  auto dma_a = [&](int u, int q) {  // piece q of this wave's share of unit u, an A image (units count from the first K step)
-    const int j = u >> 1;
-    const unsigned o = (aok[q] && j * 64 + ak[q] < Kdim) ? aoff[q] + (unsigned)j * 128u : OOB_OFF;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, smem + (u % NUNIT) * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
+  // piece q of this wave's share of the A / B image of K step j (absolute), into ring slot `slot`
+  auto dma_a = [&](int slot, int j, int q) {
+    const bool ok = !TA ? ((arow + q * 8 < p.M) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
+    const unsigned o = ok ? avo[q & 1] + ((unsigned)j * kstepA + (unsigned)q * aqs) : OOB_OFF;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, smem + slot * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
   };
-  auto dma_b = [&](int u, int q) {
-    const int j = u >> 1;
-    const unsigned o = (bok[q] && j * 64 + bk[q] < Kdim) ? boff[q] + (unsigned)j * kstepB : OOB_OFF;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, smem + (u % NUNIT) * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
+  auto dma_b = [&](int slot, int j, int q) {
+    const bool ok = !TB ? ((brow + q * 8 < p.N) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
+    const unsigned o = ok ? bvo[q & 1] + ((unsigned)j * kstepB + (unsigned)q * bqs) : OOB_OFF;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, smem + slot * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
   };
 
   f4_t acc[FM][FN];
@@ -429,33 +439,51 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
   const int wm = (w / NWN) * WM, wn = (w % NWN) * WN;
-  // fragment offsets (K half 0); the other half is `^ 64` for the swizzled K-contiguous image, `+ 32 rows` for the K-strided one
-  const int ra0 = (wm + t) * 128 + ((g ^ (t & 7)) << 4);
-  int rb[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    if (!TB) rb[j] = (wn + j * 16 + t) * 128 + ((g ^ (t & 7)) << 4);
-    else { int q = (wn >> 4) + j, key = (t >> 2) | ((g & 1) << 2); rb[j] = ((q ^ key) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BN * 2); }
-  }
-  auto read_a = [&](int u, int h, int i, s8_t& fa) {
-    fa = *reinterpret_cast<const s8_t*>(smem + (u % NUNIT) * UNIT + ((ra0 + i * 2048) ^ (h << 6)));
+  // Fragment offsets inside a unit.  K-contiguous image: fragment i of K half h at `(base + i * 2048) ^ (h << 6)`.
+  // K-strided image: fragment i sits at granule (q0 + i) ^ key of its k-rows; bits 5..7 of the offset hold only that XOR, so
+  // fragment i is `base ^ (i << 5)`; K half h is 32 k-rows further.
+  const int ra0 = !TA ? (wm + t) * 128 + ((g ^ (t & 7)) << 4)
+                      : ((((wm >> 4) ^ ((t >> 2) | ((g & 1) << 2))) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BM * 2));
+  const int rb0 = !TB ? (wn + t) * 128 + ((g ^ (t & 7)) << 4)
+                      : ((((wn >> 4) ^ ((t >> 2) | ((g & 1) << 2))) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BN * 2));
+  auto read_a = [&](int slot, int h, int i, s8_t& fa) {
+    const char* sa = smem + slot * UNIT;
+    if (!TA) fa = *reinterpret_cast<const s8_t*>(sa + (ra0 ^ (h << 6)) + i * 2048);
+    else {
+      s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + (ra0 ^ (i << 5)) + h * (32 * BM * 2)));
+      s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + (ra0 ^ (i << 5)) + h * (32 * BM * 2) + 4 * BM * 2));
+      fa = join_s4(lo, hi);
+    }
   };
-  auto read_b = [&](int u, int h, s8_t (&fb)[FN]) {
-    const char* sb = smem + (u % NUNIT) * UNIT;
+  auto read_b = [&](int slot, int h, s8_t (&fb)[FN]) {
+    const char* sb = smem + slot * UNIT;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      if (!TB) fb[j] = *reinterpret_cast<const s8_t*>(sb + (rb[j] ^ (h << 6)));
+      if (!TB) fb[j] = *reinterpret_cast<const s8_t*>(sb + (rb0 ^ (h << 6)) + j * 2048);
       else {
-        s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j] + h * (32 * BN * 2)));
-        s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + rb[j] + h * (32 * BN * 2) + 4 * BN * 2));
+        s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + (rb0 ^ (j << 5)) + h * (32 * BN * 2)));
+        s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + (rb0 ^ (j << 5)) + h * (32 * BN * 2) + 4 * BN * 2));
         fb[j] = join_s4(lo, hi);
       }
     }
   };
+  // bias gradient (sum_k A(m,k), weight-gradient products only) on the VALU slots the MFMAs leave free: on the tn == 0 tiles wave
+  // (wm, wq) sums fragments 2wq and 2wq+1, which its three wn-neighbours hold as well.  The branch is wave-uniform and contains
+  // no memory operation, so it does not disturb the counters of the pipelined loop.
+  const bool do_cs = TA && TB && p.colsum != nullptr && tn == 0;
+  const int wq = w % NWN;
+  float cs[2] = {0.f, 0.f};
   auto mma_row = [&](int i, const s8_t& fa, const s8_t (&fb)[FN]) {
 #pragma unroll
     for (int j = 0; j < FN; ++j)
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa), acc[i][j], 0, 0, 0);
+    if (TA && TB && do_cs && wq == (i >> 1)) {
+      const u4_t d = __builtin_bit_cast(u4_t, fa);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0 += __uint_as_float(d[e] << 16); s1 += __uint_as_float(d[e] & 0xFFFF0000u); }
+      cs[i & 1] += s0 + s1;
+    }
   };
   // ---- software-pipelined main loop.  A K step is 16 "rows" of 4 MFMAs (8 A fragments x 2 K halves).  The LDS reads of the next
   // half and the DMA pieces of the units freed by the step's barrier are issued one per row, between the MFMAs, so that their
@@ -463,15 +491,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
   // is re-read in place as soon as its row has been issued, only the B fragments are double-buffered (64 fragment VGPRs in all).
   // The one barrier of the step sits after row 1 of the second half: at that point every wave has all fragments of the step in
   // registers (lgkmcnt(0)), so its two units can be refilled, and has retired its own pieces of the next step's units.
-  // The body is straight-line code (a branch would make the compiler drain lgkmcnt at every block head), so the last three
-  // steps, which have fewer or no units left to fetch and nothing to prefetch, are separate instantiations (MODE 1..3).
+  // The body is straight-line code (a branch with memory operations would make the compiler drain lgkmcnt at every block head),
+  // so the last three steps, which have fewer or no units left to fetch and nothing to prefetch, are separate instantiations.
+  // Ring bookkeeping is scalar: unit u lives in slot u mod 5; `sl` is the slot of the current step's A unit.
   const int nsteps = kt_end - kt_begin, U = 2 * nsteps;
   const int issued0 = min(NUNIT - 1, U - 1);
 #pragma unroll
   for (int u = 0; u < NUNIT; ++u)
     if (u <= issued0) {
 #pragma unroll
-      for (int q = 0; q < PPU; ++q) { if (u & 1) dma_b(u, q); else dma_a(u, q); }
+      for (int q = 0; q < PPU; ++q) { if (u & 1) dma_b(u, kt_begin + (u >> 1), q); else dma_a(u, kt_begin + (u >> 1), q); }
     }
   if (issued0 >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPU) : "memory");
   else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPU) : "memory");
@@ -481,16 +510,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < FM; ++i) read_a(0, 0, i, fa[i]);
   read_b(1, 0, fb0);
-  // MODE 0: fetch units 2j+5 (B) and 2j+6 (A), prefetch the next step   1: fetch 2j+5 only   2: nothing left to fetch   3: last step
-  auto step = [&](int j, auto mode_tag) {
+  auto nxt = [](int s, int k) { s += k; return s >= NUNIT ? s - NUNIT : s; };
+  // MODE 0: fetch units 2j+5 (B of step j+2) and 2j+6 (A of step j+3), prefetch step j+1   1: fetch 2j+5 only   2: nothing left to
+  // fetch   3: last step (nothing to prefetch either)
+  auto step = [&](int jabs, int sl, auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     constexpr bool more = MODE < 3;
-    const int u0 = 2 * j;
-    read_b(u0 + 1, 1, fb1);
+    const int sl1 = nxt(sl, 1), sl2 = nxt(sl, 2), sl3 = nxt(sl, 3);
+    read_b(sl1, 1, fb1);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       mma_row(i, fa[i], fb0);
-      read_a(u0, 1, i, fa[i]);
+      read_a(sl, 1, i, fa[i]);
       __builtin_amdgcn_sched_barrier(0);
     }
     mma_row(0, fa[0], fb1);
@@ -501,37 +532,46 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (more) { read_a(u0 + 2, 0, 0, fa[0]); read_a(u0 + 2, 0, 1, fa[1]); read_b(u0 + 3, 0, fb0); }
-    if (MODE <= 1) { dma_b(u0 + 5, 0); dma_b(u0 + 5, 1); }
+    if (more) { read_a(sl2, 0, 0, fa[0]); read_a(sl2, 0, 1, fa[1]); read_b(sl3, 0, fb0); }
+    if (MODE <= 1) { dma_b(sl, jabs + 2, 0); dma_b(sl, jabs + 2, 1); }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 2; i < FM; ++i) {
       mma_row(i, fa[i], fb1);
-      if (more) read_a(u0 + 2, 0, i, fa[i]);
-      if (i < 4) { if (MODE <= 1) dma_b(u0 + 5, i); }
-      else { if (MODE == 0) dma_a(u0 + 6, i - 4); }
+      if (more) read_a(sl2, 0, i, fa[i]);
+      if (i < 4) { if (MODE <= 1) dma_b(sl, jabs + 2, i); }
+      else { if (MODE == 0) dma_a(sl1, jabs + 3, i - 4); }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  int j = 0;
-  for (; j < nsteps - 3; ++j) step(j, std::integral_constant<int, 0>{});
-  if (nsteps >= 3) step(j++, std::integral_constant<int, 1>{});
-  if (nsteps >= 2) step(j++, std::integral_constant<int, 2>{});
-  step(j, std::integral_constant<int, 3>{});
+  int j = 0, sl = 0;
+  for (; j < nsteps - 3; ++j, sl = nxt(sl, 2)) step(kt_begin + j, sl, std::integral_constant<int, 0>{});
+  if (nsteps >= 3) { step(kt_begin + j, sl, std::integral_constant<int, 1>{}); ++j; sl = nxt(sl, 2); }
+  if (nsteps >= 2) { step(kt_begin + j, sl, std::integral_constant<int, 2>{}); ++j; sl = nxt(sl, 2); }
+  step(kt_begin + j, sl, std::integral_constant<int, 3>{});
+  if (TA && TB && do_cs) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float v = cs[e];
+      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      const int m = m0 + wm + (2 * wq + e) * 16 + t;
+      if (g == 0 && m < p.M) p.colsum[(long long)split * p.M + m] = v;
+    }
+  }
   if ((dbg & 16) && acc[0][0][0] != 123456.0f) return;  // tuning aid: main loop only
   if (p.epi == EPI_ATOMIC) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        epi_dispatch(p, m0 + wm + i * 16 + t, n0 + wn + j * 16 + 4 * g, acc[i][j]);
+      for (int jj = 0; jj < FN; ++jj)
+        epi_dispatch(p, m0 + wm + i * 16 + t, n0 + wn + jj * 16 + 4 * g, acc[i][jj]);
     return;
   }
   constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
   static_assert(NW * EROWS * ESTR * 4 <= NUNIT * UNIT, "epilogue strip must fit the staging ring");
   // (no barrier: nothing has read or written the ring since the last step's barrier)
   float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
-#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
   if (p.c_dtype == CSMAE_BF16) {
     if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
     else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID); else EPI_CALL(bf16_t, EPI_NONE);
@@ -633,10 +673,10 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     // tile choice (measured on the step's shapes, tools/gemm_bench.py): 256x256 wins whenever it fits, also when it leaves
     // fewer tiles than CUs (N = 768 outputs: 150 tiles) because it halves the bytes staged per flop; 256x128 never won.
     // 0: 128x128x32 (4 waves, 2 blocks/CU)   2: 256x256x32 (8 waves, 1 block/CU)   4: 256x256x64 software-pipelined (K-contiguous A)
-    int cfg = (M >= 256 && N >= 256) ? ((!transA && splitk == 1) ? 4 : 2) : 0;
+    int cfg = (M >= 256 && N >= 256) ? (!transA ? 4 : 2) : 0;  // (K-strided A: the pipelined kernel measured 10-25 % slower than the 32-wide one)
     int stg = 4;
     if (p.force_cfg >= 0) cfg = p.force_cfg & 7; else p.force_cfg = 0;
-    if (cfg == 4 && (transA || splitk != 1)) cfg = 2;  // the 64-wide-K kernel exists for K-contiguous A, unsplit K only
+    if (cfg == 4 && transA && !transB) cfg = 2;  // (no 64-wide-K instantiation for K-strided A with K-contiguous B: unused by the step)
     if (cfg == 4) p.ktiles = cdiv(K, 64);
     (void)stg;
     const int bm = cfg == 0 ? 128 : 256, bn = cfg >= 2 ? 256 : 128;
@@ -649,8 +689,9 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     else if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, false>), grid, dim3(512), 0, st, p);  \
     else if (cfg == 3) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, true>), grid, dim3(512), 0, st, p);   \
     else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4, false>), grid, dim3(256), 0, st, p);
-    if (cfg == 4 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false>), grid, dim3(512), 0, st, p);
-    else if (cfg == 4) hipLaunchKernelGGL((gemm_bf16_k64_kernel<true>), grid, dim3(512), 0, st, p);
+    if (cfg == 4 && transA) hipLaunchKernelGGL((gemm_bf16_k64_kernel<true, true>), grid, dim3(512), 0, st, p);
+    else if (cfg == 4 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false>), grid, dim3(512), 0, st, p);
+    else if (cfg == 4) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, true>), grid, dim3(512), 0, st, p);
     else if (!transA && !transB) { LAUNCH_CFG(false, false) }
     else if (!transA && transB) { LAUNCH_CFG(false, true) }
     else if (transA && transB) { LAUNCH_CFG(true, true) }
@@ -695,11 +736,13 @@ extern int csmae_colsum_launch(int dtype, long long M, int N, const void* x, lon
 extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
                              float* dW, float* db, float* workspace, long long ws_elems, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && workspace && ws_elems >= M * N + M, "csmae_gemm_dw: bad arguments / workspace too small");
-  const int tile = dtype == CSMAE_BF16 ? ((M >= 256 && N >= 256) ? 256 : 128) : 64, kt = dtype == CSMAE_BF16 ? GEMM_BK : 16;
+  const int tile = dtype == CSMAE_BF16 ? ((M >= 256 && N >= 256) ? 256 : 128) : 64;
+  const bool k64 = dtype == CSMAE_BF16 && tile == 256 && g_force_cfg >= 0 && (g_force_cfg & 7) == 4;  // same choice as csmae_gemm makes for K-strided A
+  const int kt = dtype == CSMAE_BF16 ? (k64 ? 64 : GEMM_BK) : 16;
   const long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile), ktiles = cdiv(K, kt);
   const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? 256 : 512) : 2048;
   long long S = slots / tiles;
-  if (S > ktiles / 6) S = ktiles / 6;
+  if (S > ktiles / (k64 ? 4 : 6)) S = ktiles / (k64 ? 4 : 6);
   if (S > ws_elems / (M * N + M)) S = ws_elems / (M * N + M);
   if (S < 1) S = 1;
   const int kps = cdiv(ktiles, S);
