@@ -83,6 +83,21 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 #define GEMM_BK 32
 __device__ __forceinline__ int tr_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
+// `buffer_load_dwordx4 ... lds` as inline assembly.  Through the builtin, LLVM's waitcnt pass knows that LDS is being written by
+// VMEM and puts `s_waitcnt vmcnt(0)` in front of every later LDS read it cannot prove disjoint — which includes every
+// ds_read_b64_tr_b16 (an intrinsic without memory operands): the K-strided kernels then waited for the K-tiles they had just
+// prefetched.  The kernels below order DMA against LDS reads themselves (counted vmcnt + s_barrier), so the DMA is hidden from
+// the compiler.  LDS destination = M0 + lane * 16; an out-of-range voffset returns zeros.
+typedef int i4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i4_t make_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)ptr;
+  return i4_t{(int)(a & 0xffffffffu), (int)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void lds_dma16(i4_t rsrc, unsigned voffset, const void* lds_dst) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(const char, lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voffset), "s"(rsrc) : "memory");
+}
+
 template <bool TR, int W>   // staging descriptor of one 1-KiB DMA piece of an operand image
 struct PieceDesc {
   unsigned off; int kidx; bool ok;
@@ -178,8 +193,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
   if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
   if (p.epi == EPI_SPLIT) p.C = reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride;
 
-  auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
-  auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   const unsigned kstepA = TA ? (unsigned)(GEMM_BK * p.lda * 2) : (unsigned)(GEMM_BK * 2);
   const unsigned kstepB = TB ? (unsigned)(GEMM_BK * p.ldb * 2) : (unsigned)(GEMM_BK * 2);
 
@@ -199,10 +213,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
       const bool ok = pok[q] && (k0 + pk[q] < p.K);
       if (pi < PA) {
         unsigned o = ok ? poff[q] + (unsigned)kt * kstepA : OOB_OFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, base + pi * 1024), 16, (int)o, 0, 0, 0);
+        lds_dma16(rsA, o, base + pi * 1024);
       } else {
         unsigned o = ok ? poff[q] + (unsigned)kt * kstepB : OOB_OFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, base + A_BYTES + (pi - PA) * 1024), 16, (int)o, 0, 0, 0);
+        lds_dma16(rsB, o, base + A_BYTES + (pi - PA) * 1024);
       }
     }
   };
@@ -395,8 +409,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
   if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
   void* Cptr = p.epi == EPI_SPLIT ? static_cast<void*>(reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride) : p.C;
 
-  auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
-  auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   const unsigned kstepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
   const unsigned kstepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
 
@@ -425,12 +438,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
   auto dma_a = [&](int slot, int j, int q) {
     const bool ok = !TA ? ((arow + q * 8 < p.M) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
     const unsigned o = ok ? avo[q & 1] + ((unsigned)j * kstepA + (unsigned)q * aqs) : OOB_OFF;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, smem + slot * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
+    lds_dma16(rsA, o, smem + slot * UNIT + (w * PPU + q) * 1024);
   };
   auto dma_b = [&](int slot, int j, int q) {
     const bool ok = !TB ? ((brow + q * 8 < p.N) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
     const unsigned o = ok ? bvo[q & 1] + ((unsigned)j * kstepB + (unsigned)q * bqs) : OOB_OFF;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, smem + slot * UNIT + (w * PPU + q) * 1024), 16, (int)o, 0, 0, 0);
+    lds_dma16(rsB, o, smem + slot * UNIT + (w * PPU + q) * 1024);
   };
 
   f4_t acc[FM][FN];
@@ -673,7 +686,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     // tile choice (measured on the step's shapes, tools/gemm_bench.py): 256x256 wins whenever it fits, also when it leaves
     // fewer tiles than CUs (N = 768 outputs: 150 tiles) because it halves the bytes staged per flop; 256x128 never won.
     // 0: 128x128x32 (4 waves, 2 blocks/CU)   2: 256x256x32 (8 waves, 1 block/CU)   4: 256x256x64 software-pipelined (K-contiguous A)
-    int cfg = (M >= 256 && N >= 256) ? (!transA ? 4 : 2) : 0;  // (K-strided A: the pipelined kernel measured 10-25 % slower than the 32-wide one)
+    int cfg = (M >= 256 && N >= 256) ? ((!transA || transB) ? 4 : 2) : 0;
     int stg = 4;
     if (p.force_cfg >= 0) cfg = p.force_cfg & 7; else p.force_cfg = 0;
     if (cfg == 4 && transA && !transB) cfg = 2;  // (no 64-wide-K instantiation for K-strided A with K-contiguous B: unused by the step)
@@ -737,7 +750,7 @@ extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, c
                              float* dW, float* db, float* workspace, long long ws_elems, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && workspace && ws_elems >= M * N + M, "csmae_gemm_dw: bad arguments / workspace too small");
   const int tile = dtype == CSMAE_BF16 ? ((M >= 256 && N >= 256) ? 256 : 128) : 64;
-  const bool k64 = dtype == CSMAE_BF16 && tile == 256 && g_force_cfg >= 0 && (g_force_cfg & 7) == 4;  // same choice as csmae_gemm makes for K-strided A
+  const bool k64 = dtype == CSMAE_BF16 && tile == 256 && (g_force_cfg < 0 || (g_force_cfg & 7) == 4);  // same choice as csmae_gemm
   const int kt = dtype == CSMAE_BF16 ? (k64 ? 64 : GEMM_BK) : 16;
   const long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile), ktiles = cdiv(K, kt);
   const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? 256 : 512) : 2048;
