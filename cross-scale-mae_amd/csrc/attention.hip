@@ -50,6 +50,15 @@ __device__ __forceinline__ s8_t pack_pair(f4_t a, f4_t b) {
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------ bf16 forward
+// With 32-wide heads two neighbouring heads share every 128-B line of a qkv row.  Workgroups are dealt to the 8 XCDs round-robin,
+// so consecutive (sample, head) ids land on different L2s and each line is fetched from HBM twice (measured: FETCH_SIZE = 2x the
+// algorithmic bytes).  Inside each run of 16 ids, ids x and x + 8 (same XCD, back to back) take heads 2x' and 2x' + 1.
+template <int HD>
+__device__ __forceinline__ int pair_remap(int bid, int nblk) {
+  if (HD * 2 >= 128 || (bid | 15) >= nblk) return bid;
+  return (bid & ~15) + 2 * (bid & 7) + ((bid >> 3) & 1);
+}
+
 template <int HD, int NKF>
 __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                      float* __restrict__ lse, int T, int H, int D, int hd, float scale) {
@@ -58,7 +67,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
   char* Ks = smem;
   char* Vs = smem + TP * AttnLds<HD>::STRIDE;
   char* Qs = smem + 2 * TP * AttnLds<HD>::STRIDE;  // Q too: a per-q-block global fetch would expose ~1 us of latency per block
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int wid = pair_remap<HD>(blockIdx.x, gridDim.x);
+  const int b = wid / H, h = wid - b * H;
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
   stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);
@@ -125,7 +135,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
   char* Qs = smem; char* Ks = smem + IMG; char* Vs = smem + 2 * IMG; char* Gs = smem + 3 * IMG;  // Gs = dO
   float* lse2 = reinterpret_cast<float*>(smem + 4 * IMG);  // log2-domain LSE, +inf on padded rows
   float* dl = lse2 + TP;                                     // D_i = sum_d dO_i . O_i
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int wid = pair_remap<HD>(blockIdx.x, gridDim.x);
+  const int b = wid / H, h = wid - b * H;
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
   stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);

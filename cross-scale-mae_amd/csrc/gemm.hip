@@ -18,6 +18,7 @@
 // fp32 path: exact-fp32 FMA tile kernel used for the 1e-4 parity mode (not the throughput path).
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 #define EPI_NONE 0    // C = acc + bias
 #define EPI_GELU 1    // x = acc + bias ; C = gelu(x) ; aux = gelu'(x)
@@ -753,7 +754,8 @@ extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, c
   const bool k64 = dtype == CSMAE_BF16 && tile == 256 && (g_force_cfg < 0 || (g_force_cfg & 7) == 4);  // same choice as csmae_gemm
   const int kt = dtype == CSMAE_BF16 ? (k64 ? 64 : GEMM_BK) : 16;
   const long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile), ktiles = cdiv(K, kt);
-  const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? 256 : 512) : 2048;
+  static const int slots256 = getenv("CSMAE_DW_SLOTS") ? atoi(getenv("CSMAE_DW_SLOTS")) : 128;  // blocks per weight-gradient GEMM (tuning aid). Half the CUs: the other half runs the main stream, and the slab traffic halves
+  const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? slots256 : 512) : 2048;
   long long S = slots / tiles;
   if (S > ktiles / (k64 ? 4 : 6)) S = ktiles / (k64 ? 4 : 6);
   if (S > ws_elems / (M * N + M)) S = ws_elems / (M * N + M);
