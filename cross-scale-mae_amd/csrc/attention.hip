@@ -10,6 +10,7 @@
 // recomputed in each pass (attention is 3.7 % of the step's FLOPs; this avoids cross-wave reductions).
 // fp32 path: exact fp32 (parity mode), one thread per query row / key column.
 #include "common.h"
+#include <cstdlib>
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
@@ -247,6 +248,178 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------ bf16 backward, single pass
+// One workgroup (4 waves) per (sample, head).  A wave owns PAIRS of 16-key tiles (32 keys: pair w in the first sweep, pair w + 4
+// in the second) and walks all query-tile pairs once per sweep:
+//   S, dP  : lane <-> key, registers <-> queries  -> P and dS are directly the k-packed operands of the contractions over queries
+//   dV, dK : accumulate in the wave's registers (it owns those keys)
+//   dQ     : contracts over keys, i.e. needs dS with lane <-> query: each dS tile takes one 512-B round trip through a wave-private
+//            LDS patch (ds_write_b64, ds_read_b64_tr_b16) instead of recomputing S, dP and the exponentials in a second pass.
+//            The partial dQ of a (query pair, key pair) is added into an fp32 LDS accumulator with plain read-modify-write: in
+//            step s wave w works on query pair (w + s) mod NQ, so no two waves touch the same rows between two barriers.
+//            (LDS float atomics were measured at ~700 clk per ds_add_f32 wave-instruction here: 3x slower than two passes.)
+// Only Q and dO are staged for the whole head; K and V fragments come straight from global memory (each key is needed by one
+// wave), K^T through the wave's patch.  78 KiB of LDS and < 256 registers: two workgroups per CU, so one head's loads overlap the
+// other's arithmetic — the two-pass kernel above needs 432 registers and 73 KiB and runs one workgroup per CU, latency-bound.
+template <int HD, int NKF>
+struct AttnBwd1p {
+  static constexpr int NP = NKF / 2, TP = NKF * 16, IMG = TP * AttnLds<HD>::STRIDE, QS = HD + 4;
+  static constexpr int XB = 32 * HD * 2;  // per wave: 4 dS tiles (bf16 [16 keys][16 queries]) or the wave's 32 K rows
+  static constexpr int LDS = 2 * IMG + TP * QS * 4 + 4 * XB + 2 * TP * 4;
+};
+template <int HD>  // transposed fragment from an unpadded [rows][HD] bf16 patch (same k order as frag_cols_tr)
+__device__ __forceinline__ s8_t patch_cols_tr(const char* img, int c0, int t, int g) {
+  const char* p = img + (4 * g + (t >> 2)) * (HD * 2) + (c0 + (t & 3) * 4) * 2;
+  s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, p));
+  s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, p + 16 * HD * 2));
+  return join_s4(lo, hi);
+}
+template <int HD, int NKF>
+__global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale) {
+  using L = AttnBwd1p<HD, NKF>;
+  constexpr int TP = L::TP, NP = L::NP, KS = HD / 32, DF = HD / 16, IMG = L::IMG, QS = L::QS;
+  __shared__ __attribute__((aligned(16))) char smem[L::LDS];
+  char* Qs = smem; char* Gs = smem + IMG;                                // Gs = dO
+  float* dqa = reinterpret_cast<float*>(smem + 2 * IMG);                 // dQ accumulator [TP][QS]
+  char* xall = smem + 2 * IMG + TP * QS * 4;
+  float* lse2 = reinterpret_cast<float*>(xall + 4 * L::XB);              // log2-domain LSE, +inf on padded rows
+  float* dl = lse2 + TP;                                                 // D_i = sum_d dO_i . O_i
+  const int wid = pair_remap<HD>(blockIdx.x, gridDim.x);
+  const int b = wid / H, h = wid - b * H;
+  const long long row0 = (long long)b * T;
+  const int ld = 3 * D;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);
+  stage_head<HD, TP>(Gs, dout, row0, D, h * hd, T, hd);
+  for (int e = threadIdx.x; e < TP * QS / 4; e += blockDim.x) reinterpret_cast<f4_t*>(dqa)[e] = f4_t{0.f, 0.f, 0.f, 0.f};
+  for (int r = threadIdx.x; r < TP; r += blockDim.x) {
+    float acc = 0.f, l2 = INFINITY;
+    if (r < T) {
+      l2 = lse[((long long)b * H + h) * T + r] * LOG2E;
+      const bf16_t* o = out + (row0 + r) * D + h * hd;
+      const bf16_t* gg = dout + (row0 + r) * D + h * hd;
+      uint4 ov[HD / 8], gv[HD / 8];
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        ov[c] = c * 8 < hd ? *reinterpret_cast<const uint4*>(o + c * 8) : make_uint4(0, 0, 0, 0);
+        gv[c] = c * 8 < hd ? *reinterpret_cast<const uint4*>(gg + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        const unsigned ow[4] = {ov[c].x, ov[c].y, ov[c].z, ov[c].w}, gw[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          acc += __uint_as_float(ow[k] << 16) * __uint_as_float(gw[k] << 16) + __uint_as_float(ow[k] & 0xffff0000u) * __uint_as_float(gw[k] & 0xffff0000u);
+      }
+    }
+    lse2[r] = l2; dl[r] = acc;
+  }
+  const float c2 = scale * LOG2E;
+  char* xw = xall + w * L::XB;              // this wave's patch
+  const int nq = (T + 31) >> 5;             // query-tile pairs that hold real rows
+  const int nkp = (T + 31) >> 5;            // key pairs that hold real rows
+  for (int sweep = 0; sweep * 4 < nkp; ++sweep) {
+    const int kp = sweep * 4 + w;
+    const bool active = kp < nkp;           // (wave-uniform) the last sweep may have fewer pairs than waves
+    const int k0 = 32 * kp;
+    // K, V rows of the two key tiles straight from global memory; K^T (k = keys) through the patch
+    s8_t fk[2][KS], fv[2][KS], kT[DF];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int key = k0 + 16 * jj + t, col = ks * 32 + 8 * g;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (active && key < T && col < hd) {
+          kv = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + D + h * hd + col);
+          vv = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + 2 * D + h * hd + col);
+        }
+        fk[jj][ks] = __builtin_bit_cast(s8_t, kv); fv[jj][ks] = __builtin_bit_cast(s8_t, vv);
+        *reinterpret_cast<uint4*>(xw + (16 * jj + t) * (HD * 2) + col * 2) = kv;
+      }
+#pragma unroll
+    for (int df = 0; df < DF; ++df) kT[df] = patch_cols_tr<HD>(xw, df * 16, t, g);
+    f4_t dk[2][DF], dv[2][DF];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int df = 0; df < DF; ++df) { dk[jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; dv[jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; }
+    __syncthreads();                        // (first sweep: staging visible; later sweeps: previous sweep's last dQ update done)
+    for (int s = 0; s < nq; ++s) {
+      int ip = w + s; if (ip >= nq) ip -= nq;
+      const int q0 = 32 * ip;
+      if (active && w < nq) {
+        f4_t p[2][2], ds[2][2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          s8_t fq[KS], fg[KS];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) { fq[ks] = frag_rows<HD>(Qs, q0 + 16 * ii, ks, t, g); fg[ks] = frag_rows<HD>(Gs, q0 + 16 * ii, ks, t, g); }
+          const f4_t l4 = *reinterpret_cast<const f4_t*>(lse2 + q0 + 16 * ii + 4 * g);
+          const f4_t d4 = *reinterpret_cast<const f4_t*>(dl + q0 + 16 * ii + 4 * g);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            f4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { a = MFMA16(fq[ks], fk[jj][ks], a); dp = MFMA16(fg[ks], fv[jj][ks], dp); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              p[ii][jj][r] = __builtin_amdgcn_exp2f(a[r] * c2 - l4[r]);  // padded queries: lse2 = +inf -> p = 0
+              ds[ii][jj][r] = p[ii][jj][r] * (dp[r] - d4[r]) * scale;
+            }
+            // dS tile -> patch [ii][jj][key t][query 4g..4g+3] (bf16)
+            uint2 u = make_uint2(pack2bf(ds[ii][jj][0], ds[ii][jj][1]), pack2bf(ds[ii][jj][2], ds[ii][jj][3]));
+            *reinterpret_cast<uint2*>(xw + (ii * 2 + jj) * 512 + t * 32 + g * 8) = u;
+          }
+        }
+        // dK, dV: contraction over the 32 queries of the pair (k order {4g+e, 16+4g+e}: what pack_pair and frag_cols_tr share)
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+          const s8_t qT = frag_cols_tr<HD>(Qs, q0, df * 16, t, g), gT = frag_cols_tr<HD>(Gs, q0, df * 16, t, g);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            dk[jj][df] = MFMA16(qT, pack_pair(ds[0][jj], ds[1][jj]), dk[jj][df]);
+            dv[jj][df] = MFMA16(gT, pack_pair(p[0][jj], p[1][jj]), dv[jj][df]);
+          }
+        }
+        // dQ: contraction over this wave's 32 keys; lane <-> query through the transposing read of the patch
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const char* xp = xw + ii * 1024 + (4 * g + (t >> 2)) * 32 + (t & 3) * 8;
+          s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, xp));
+          s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, xp + 512));
+          const s8_t sT = join_s4(lo, hi);
+          f4_t* dst = reinterpret_cast<f4_t*>(dqa + (q0 + 16 * ii + t) * QS + 4 * g);
+#pragma unroll
+          for (int df = 0; df < DF; ++df) dst[df * 4] = MFMA16(kT[df], sT, dst[df * 4]);
+        }
+      }
+      __syncthreads();                      // the rows this wave updated belong to another wave in the next step
+    }
+    // dK, dV of the wave's keys
+    if (active) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int key = k0 + 16 * jj + t;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+          const int d = df * 16 + 4 * g;
+          if (key < T && d < hd) {
+            st4<bf16_t>(dqkv + (row0 + key) * ld + D + h * hd + d, dk[jj][df]);
+            st4<bf16_t>(dqkv + (row0 + key) * ld + 2 * D + h * hd + d, dv[jj][df]);
+          }
+        }
+      }
+    }
+  }
+  for (int e = threadIdx.x; e < T * (HD / 4); e += blockDim.x) {
+    const int q = e / (HD / 4), d = (e - q * (HD / 4)) * 4;
+    if (d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d));
+  }
+}
+
 // ------------------------------------------------------------------------------------------ fp32 (parity mode)
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qkv, float* __restrict__ out,
@@ -359,7 +532,12 @@ static void launch_fwd_bf16(int BH, const void* qkv, void* out, float* lse, int 
 }
 template <int HD, int NKF>
 static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int T, int H, int D, int hd, float scale, hipStream_t st) {
-  hipLaunchKernelGGL((attn_bwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
+  static const bool two_pass = getenv("CSMAE_ATTN_BWD_2PASS") != nullptr;  // tuning aid: the older two-pass kernel
+  if (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 && NKF >= 6 && !two_pass)  // (<= 64 tokens: fewer key pairs than waves, the two-pass split is faster)
+    hipLaunchKernelGGL((attn_bwd1p_bf16<HD, (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
+  else
+    hipLaunchKernelGGL((attn_bwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
 }
 
 // (head_dim bucket, key-fragment count) combinations whose LDS images fit 160 KiB in the backward kernel
@@ -421,4 +599,11 @@ extern "C" int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, cons
     else hipLaunchKernelGGL((attn_bwd_f32<96>), dim3(BH), dim3(256), sh, st, (const float*)qkv, (const float*)out, (const float*)dout, lse, (float*)dqkv, T, H, D, hd, scale);
   } else { csmae_set_error("csmae_attn_bwd: unsupported dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_attn_bwd");
+}
+
+// tuning aid (not in include/csmae.h): resident workgroups per CU the runtime computes for the two decoder-shape kernels
+extern "C" int csmae_debug_attn_occupancy(int* fwd, int* bwd) {
+  hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(fwd, attn_fwd_bf16<32, 14>, 256, 0);
+  hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(bwd, attn_bwd_bf16<32, 14>, 256, 0);
+  return (int)e1 * 1000 + (int)e2;
 }
