@@ -58,42 +58,66 @@ class FusedAdamW(torch.optim.Optimizer):
         active = tuple(id(p) for p in group["params"] if p.grad is not None)
         key = (gi, active)
         if key not in self._plans:
-            offs, cnts = [], []
+            self._sync_steps()
+            offs, cnts, params = [], [], []
             for p in group["params"]:
                 if p.grad is None:
                     continue
+                params.append(p)
                 off, n, _ = flat.slot_of(p)
-                if p.grad.data_ptr() != flat.g.data_ptr() + off * 4:
-                    flat.g[off:off + n].view(p.shape).copy_(p.grad)  # foreign gradient tensor: bring it home
                 for o in range(0, n, self.TILE):
                     offs.append(off + o)
                     cnts.append(min(self.TILE, n - o))
             dev = flat.p.device
-            self._plans[key] = (torch.tensor(offs, dtype=torch.long, device=dev), torch.tensor(cnts, dtype=torch.int32, device=dev),
-                                torch.full((len(offs),), float(group["weight_decay"]), device=dev), torch.zeros(6, device=dev),
-                                torch.zeros(6).pin_memory() if torch.cuda.is_available() else torch.zeros(6))
+            wd = float(group["weight_decay"])
+            self._plans[key] = dict(off=torch.tensor(offs, dtype=torch.long, device=dev), cnt=torch.tensor(cnts, dtype=torch.int32, device=dev),
+                                    wd=torch.full((len(offs),), wd, device=dev), wd_host=wd, hyper=torch.zeros(6, device=dev),
+                                    host=torch.zeros(6).pin_memory() if torch.cuda.is_available() else torch.zeros(6), params=params,
+                                    step=int(self.state[params[0]]["step"]) if params else 0)
         return self._plans[key]
 
     @torch.no_grad()
     def step(self, closure=None):
+        """No host<->device synchronisation in here: the hyper-parameters travel through a pinned buffer, the step counter and the
+        weight decay live on the host, so the CPU keeps enqueueing the next step while the GPU is still in this one's backward."""
         loss = closure() if closure is not None else None
         flat = self._bind()
+        g0 = flat.g.data_ptr()
         for gi, group in enumerate(self.param_groups):
-            params = [p for p in group["params"] if p.grad is not None]
+            plan = self._plan(gi, group, flat)
+            params = plan["params"]
             if not params:
                 continue
-            step = int(self.state[params[0]]["step"]) + 1
-            toff, tcnt, twd, hyper, host = self._plan(gi, group, flat)
-            if twd.numel() and float(group["weight_decay"]) != float(twd[0]):
-                twd.fill_(float(group["weight_decay"]))
+            for p in params:  # a gradient tensor that is not the engine's view of the flat buffer: bring it home
+                if p.grad.data_ptr() - g0 != flat.slot_of(p)[0] * 4:
+                    off, n, _ = flat.slot_of(p)
+                    flat.g[off:off + n].view(p.shape).copy_(p.grad)
+            plan["step"] += 1
+            step = plan["step"]
+            wd = float(group["weight_decay"])
+            if wd != plan["wd_host"]:
+                plan["wd"].fill_(wd)
+                plan["wd_host"] = wd
             b1, b2 = group["betas"]
-            host.copy_(torch.tensor([group["lr"], b1, b2, group["eps"], 1 - b1 ** step, 1 - b2 ** step]))
-            hyper.copy_(host, non_blocking=True)
-            ops.adamw(toff, tcnt, twd, flat.p, flat.g, self._m, self._v, hyper, p_lp=flat.w_lp)
-            for p in params:
-                self.state[p]["step"] = torch.tensor(float(step))
+            plan["host"].copy_(torch.tensor([group["lr"], b1, b2, group["eps"], 1 - b1 ** step, 1 - b2 ** step]))
+            plan["hyper"].copy_(plan["host"], non_blocking=True)
+            ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, plan["hyper"], p_lp=flat.w_lp)
+            self._dirty_steps = True
         return loss
+
+    def _sync_steps(self):
+        """torch's per-parameter `step` entries are refreshed lazily (state_dict / checkpointing), not 250 tensors per step."""
+        if getattr(self, "_dirty_steps", False):
+            for plan in self._plans.values():
+                for p in plan["params"]:
+                    self.state[p]["step"] = torch.tensor(float(plan["step"]))
+            self._dirty_steps = False
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._flat = None  # re-alias the loaded moments into the flat buffers at the next step
+        self._dirty_steps = False
