@@ -198,7 +198,8 @@ class Engine:
                 self.w_pe_pad = torch.zeros(cfg["D"], self.Pp, device=self.device, dtype=torch.bfloat16)
                 self.w_pred_pad = torch.zeros(self.Pp, cfg["Dd"], device=self.device, dtype=torch.bfloat16)
         self.ws: Optional[Workspace] = None
-        self.lp_fresh = False
+        self.lp_fresh = False  # (kept for callers that still set it; the mirror is tracked by version, see _refresh_lp)
+        self._lp_ver = None
         self._saved = None
         self.side, self.main = None, None
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
@@ -212,13 +213,19 @@ class Engine:
         return t.view(t.shape[0], -1) if t.dim() > 1 else t
 
     def _refresh_lp(self):
-        if self.T == BF16 and not self.lp_fresh:
+        """Bring the bf16 weight mirror up to date.  FusedAdamW writes the mirror in the same kernel that steps the fp32 master (through
+        raw pointers: the tensor version does not move), so a full recast (0.7 GB of HBM traffic for ViT-B) is only needed when somebody
+        else has written the parameters in place — torch.optim, load_state_dict, manual edits — which bumps `flat.p._version`."""
+        if self.T != BF16:
+            return
+        ver = self.flat.p._version
+        if ver != self._lp_ver:
             ops.cast_bf16(self.flat.p, self.flat.w_lp)
-            if self.Pp != self.cfg["P"]:
-                P = self.cfg["P"]
-                self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
-                self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
-            self.lp_fresh = True
+            self._lp_ver = ver
+        if self.Pp != self.cfg["P"]:
+            P = self.cfg["P"]
+            self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
+            self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
 
     def _w_pe(self):
         if self.T == BF16 and self.Pp != self.cfg["P"]:

@@ -218,9 +218,11 @@ def loss_finalize(per_view, views, rowloss, mask, recon_scale, losses, cd_partia
                                      _p(ce_rowloss), ce_rows, _p(losses), st if st is not None else stream()), "csmae_loss_finalize")
 
 
-def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, hyper, p_lp=None, st=None):
-    check(load().csmae_adamw(tile_off.numel(), _p(tile_off), _p(tile_cnt), _p(tile_wd), _p(p), _p(g), _p(m), _p(v), _p(hyper), _p(p_lp),
-                             st if st is not None else stream()), "csmae_adamw")
+def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps, step, p_lp=None, st=None):
+    """One fused AdamW step over the tiles; `step` (1-based) sets the bias corrections 1 - beta^step."""
+    check(load().csmae_adamw(tile_off.numel(), _p(tile_off), _p(tile_cnt), _p(tile_wd), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1),
+                             float(beta2), float(eps), 1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(p_lp), st if st is not None else stream()),
+          "csmae_adamw")
 
 
 def cast_bf16(src, dst, st=None):

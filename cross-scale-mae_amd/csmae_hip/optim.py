@@ -71,15 +71,14 @@ class FusedAdamW(torch.optim.Optimizer):
             dev = flat.p.device
             wd = float(group["weight_decay"])
             self._plans[key] = dict(off=torch.tensor(offs, dtype=torch.long, device=dev), cnt=torch.tensor(cnts, dtype=torch.int32, device=dev),
-                                    wd=torch.full((len(offs),), wd, device=dev), wd_host=wd, hyper=torch.zeros(6, device=dev),
-                                    host=torch.zeros(6).pin_memory() if torch.cuda.is_available() else torch.zeros(6), params=params,
+                                    wd=torch.full((len(offs),), wd, device=dev), wd_host=wd, params=params,
                                     step=int(self.state[params[0]]["step"]) if params else 0)
         return self._plans[key]
 
     @torch.no_grad()
     def step(self, closure=None):
-        """No host<->device synchronisation in here: the hyper-parameters travel through a pinned buffer, the step counter and the
-        weight decay live on the host, so the CPU keeps enqueueing the next step while the GPU is still in this one's backward."""
+        """No host<->device synchronisation and no staging copies in here: the hyper-parameters are kernel arguments, the step counter
+        and the weight decay live on the host, so the CPU keeps enqueueing the next step while the GPU is still in this one's backward."""
         loss = closure() if closure is not None else None
         flat = self._bind()
         g0 = flat.g.data_ptr()
@@ -99,9 +98,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 plan["wd"].fill_(wd)
                 plan["wd_host"] = wd
             b1, b2 = group["betas"]
-            plan["host"].copy_(torch.tensor([group["lr"], b1, b2, group["eps"], 1 - b1 ** step, 1 - b2 ** step]))
-            plan["hyper"].copy_(plan["host"], non_blocking=True)
-            ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, plan["hyper"], p_lp=flat.w_lp)
+            ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp)
             self._dirty_steps = True
         return loss
 

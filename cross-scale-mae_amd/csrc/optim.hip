@@ -6,15 +6,15 @@
 //   colsum     bias gradients: db[n] += sum_m dY[m, n]
 #include "common.h"
 
-// hyper (device, fp32): [0]=lr [1]=beta1 [2]=beta2 [3]=eps [4]=bias_correction1 [5]=bias_correction2
+// hyper-parameters travel by value (kernel arguments): no device-side staging buffer whose host copy could be overwritten by a
+// CPU that runs a step ahead of the GPU
 __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict__ tile_off, const int* __restrict__ tile_cnt,
                                                     const float* __restrict__ tile_wd, float* __restrict__ p, const float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, const float* __restrict__ hyper,
-                                                    bf16_t* __restrict__ p_lp) {
+                                                    float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2, float eps,
+                                                    float bc1, float bc2, bf16_t* __restrict__ p_lp) {
   const long long off = tile_off[blockIdx.x];
   const int cnt = tile_cnt[blockIdx.x];
   const float wd = tile_wd[blockIdx.x];
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2 = hyper[5];
   const float step_size = lr / bc1, rbc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
   for (int i = threadIdx.x * 4; i < cnt; i += blockDim.x * 4) {
     if (i + 4 <= cnt && ((off + i) & 3) == 0) {
@@ -42,9 +42,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict_
   }
 }
 extern "C" int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
-                           float* m, float* v, const float* hyper, void* p_lp, void* stream) {
-  CSMAE_REQUIRE(ntiles > 0 && tile_off && tile_cnt && tile_wd && p && g && m && v && hyper, "csmae_adamw: null argument");
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, tile_off, tile_cnt, tile_wd, p, g, m, v, hyper, (bf16_t*)p_lp);
+                           float* m, float* v, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
+                           void* p_lp, void* stream) {
+  CSMAE_REQUIRE(ntiles > 0 && tile_off && tile_cnt && tile_wd && p && g && m && v, "csmae_adamw: null argument");
+  CSMAE_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, "csmae_adamw: bias corrections must be positive (step >= 1)");
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps,
+                     bias_correction1, bias_correction2, (bf16_t*)p_lp);
   return csmae_check_launch("csmae_adamw");
 }
 

@@ -126,7 +126,8 @@ int csmae_loss_finalize(long long per_view, int views, const float* rowloss, con
 
 /* ---- optimizer side (main_pretrain.py:426-427 torch.optim.AdamW; util/misc.py:314 backward products) */
 int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
-                float* m, float* v, const float* hyper, void* p_lp, void* stream);
+                float* m, float* v, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
+                void* p_lp, void* stream);
 int csmae_cast_f32_to_bf16(long long n, const float* src, void* dst, void* stream);
 int csmae_colsum(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream);
 

@@ -446,8 +446,7 @@ def test_adamw_matches_torch(ops):
             p.grad = rnd(sizes[i], seed=200 + 10 * step + i)
             flat_g[offs[i]:offs[i] + sizes[i]] = p.grad
         opt.step()
-        hyper = torch.tensor([1e-3, 0.9, 0.95, 1e-8, 1 - 0.9 ** step, 1 - 0.95 ** step], device="cuda")
-        ops.adamw(toff, tcnt, twd, gp, flat_g.cuda(), m, v, hyper, p_lp=lp)
+        ops.adamw(toff, tcnt, twd, gp, flat_g.cuda(), m, v, 1e-3, 0.9, 0.95, 1e-8, step, p_lp=lp)
         for i, p in enumerate(tp):
             assert_close(gp[offs[i]:offs[i] + sizes[i]], p, 1e-6, 1e-7, f"adamw step {step} tensor {i}")
     assert_close(lp[:1000], gp[:1000], 1e-2, 1e-3, "bf16 mirror")
