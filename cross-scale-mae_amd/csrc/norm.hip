@@ -61,8 +61,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
   }
   for (long long row = (long long)blockIdx.x * 4 + w; row < M; row += (long long)gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
-    f4_t g[NV], xh[NV];
+    f4_t g[NV], xh[NV], dr[NV];
     float s1 = 0.f, s2 = 0.f;
+    // every load of the row is issued before the first reduction: the residual gradient does not depend on the row statistics,
+    // and fetching it only after the two wave reductions left each wave with a second, serialised HBM round trip per row
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + i * 64;
+      dr[i] = (dres_in && c < nv) ? *reinterpret_cast<const f4_t*>(dres_in + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = lane + i * 64;
@@ -81,8 +88,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
     for (int i = 0; i < NV; ++i) {
       int c = lane + i * 64;
       if (c < nv) {
-        f4_t dx = (g[i] - s1 - xh[i] * s2) * rs;
-        if (dres_in) dx += *reinterpret_cast<const f4_t*>(dres_in + row * D + c * 4);
+        f4_t dx = (g[i] - s1 - xh[i] * s2) * rs + dr[i];
         *reinterpret_cast<f4_t*>(dx_out + row * D + c * 4) = dx;
         if (dx_lp) st4<TLP>(dx_lp + row * D + c * 4, dx);
       }
