@@ -393,10 +393,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
 // (all 160 KiB), one unit = one operand's [256 x 64] image; a K step consumes units (2j, 2j+1) while 2j+2 .. 2j+4 are in flight.
 //   K-contiguous image: [256 rows][64 k], 128-B rows, 16-B chunk swizzle c ^ (row & 7) (conflict-free ds_read_b128)
 //   K-strided image   : two [32 k][256] images of the 32-wide kernel back to back (ds_read_b64_tr_b16)
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
-  constexpr int BM = 256, BN = 256, WM = 128, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
-  constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;
+template <bool TA, bool TB, int BM = 256>  // BM = 192 (K-contiguous A only): 6 instead of 8 A fragments per wave, for outputs whose 256-row
+__global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  // tiling leaves too many CUs idle (N = 768: 150 -> 201 tiles)
+  static_assert(BM == 256 || (BM == 192 && !TA), "192-row tiles exist for K-contiguous A only");
+  constexpr int BN = 256, WM = BM / 2, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
+  constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;  // ring slot = 32 KiB; a B image fills it, a 192-row A image uses 24 KiB
+  constexpr int PPA = BM * 64 * 2 / 1024 / NW;                            // DMA pieces per wave of an A image (4 or 3)
   __shared__ __attribute__((aligned(16))) char smem[NUNIT * UNIT];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = lane & 15, g = lane >> 4;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
   const int kc = ((lane & 7) ^ l3) * 8;
   auto tr_ch = [&](int qodd) { const int key = l5 | (qodd << 1) | ((w & 1) << 2); return (((s16 >> 1) ^ key) << 1) | (s16 & 1); };
   unsigned avo[2], bvo[2];
-  if (!TA) avo[0] = avo[1] = (unsigned)(((long long)(m0 + w * 32 + l3) * p.lda + kc) * 2);
+  if (!TA) avo[0] = avo[1] = (unsigned)(((long long)(m0 + w * (PPA * 8) + l3) * p.lda + kc) * 2);
   else {
     avo[0] = (unsigned)(((long long)(w * 8 + l5) * p.lda + m0 + tr_ch(0) * 8) * 2);
     avo[1] = (unsigned)(((long long)(w * 8 + l5) * p.lda + m0 + tr_ch(1) * 8) * 2);
@@ -433,13 +435,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
     bvo[1] = (unsigned)(((long long)(w * 8 + l5) * p.ldb + n0 + tr_ch(1) * 8) * 2);
   }
   const unsigned aqs = (unsigned)((TA ? 2 : 8) * p.lda * 2), bqs = (unsigned)((TB ? 2 : 8) * p.ldb * 2);  // advance per piece
-  const int arow = m0 + w * 32 + l3, brow = n0 + w * 32 + l3, krow = w * 8 + l5;
+  const int arow = m0 + w * (PPA * 8) + l3, brow = n0 + w * 32 + l3, krow = w * 8 + l5;
   const int dbg = p.force_cfg;  // tuning aid (csmae_gemm_force_tile): 16 = main loop only
   // piece q of this wave's share of the A / B image of K step j (absolute), into ring slot `slot`
   auto dma_a = [&](int slot, int j, int q) {
     const bool ok = !TA ? ((arow + q * 8 < p.M) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
     const unsigned o = ok ? avo[q & 1] + ((unsigned)j * kstepA + (unsigned)q * aqs) : OOB_OFF;
-    lds_dma16(rsA, o, smem + slot * UNIT + (w * PPU + q) * 1024);
+    lds_dma16(rsA, o, smem + slot * UNIT + (w * PPA + q) * 1024);
   };
   auto dma_b = [&](int slot, int j, int q) {
     const bool ok = !TB ? ((brow + q * 8 < p.N) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
@@ -514,10 +516,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
   for (int u = 0; u < NUNIT; ++u)
     if (u <= issued0) {
 #pragma unroll
-      for (int q = 0; q < PPU; ++q) { if (u & 1) dma_b(u, kt_begin + (u >> 1), q); else dma_a(u, kt_begin + (u >> 1), q); }
+      for (int q = 0; q < PPU; ++q) { if (u & 1) dma_b(u, kt_begin + (u >> 1), q); else if (q < PPA) dma_a(u, kt_begin + (u >> 1), q); }
     }
-  if (issued0 >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPU) : "memory");
-  else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPU) : "memory");
+  if (issued0 >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPA + PPU) : "memory");  // units 2 (A), 3 (B), 4 (A) may stay in flight
+  else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPA + PPU) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   s8_t fa[FM], fb0[FN], fb1[FN];
@@ -541,20 +543,26 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {
     mma_row(0, fa[0], fb1);
     mma_row(1, fa[1], fb1);
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPU) : "memory");  // own pieces of units 2j+2, 2j+3 (2j+4 may stay in flight)
+    if (MODE <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPA) : "memory");  // own pieces of units 2j+2, 2j+3 (2j+4, an A image, may stay in flight)
     else if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (more) { read_a(sl2, 0, 0, fa[0]); read_a(sl2, 0, 1, fa[1]); read_b(sl3, 0, fb0); }
-    if (MODE <= 1) { dma_b(sl, jabs + 2, 0); dma_b(sl, jabs + 2, 1); }
+    // the PPU + PPA pieces of the two units: one per remaining row, the surplus right here
+    constexpr int NPC = PPU + PPA, FIRST = NPC - (FM - 2);
+    auto piece = [&](int pc) {
+      if (pc < PPU) { if (MODE <= 1) dma_b(sl, jabs + 2, pc); }
+      else { if (MODE == 0) dma_a(sl1, jabs + 3, pc - PPU); }
+    };
+#pragma unroll
+    for (int pc = 0; pc < FIRST; ++pc) piece(pc);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 2; i < FM; ++i) {
       mma_row(i, fa[i], fb1);
       if (more) read_a(sl2, 0, i, fa[i]);
-      if (i < 4) { if (MODE <= 1) dma_b(sl, jabs + 2, i); }
-      else { if (MODE == 0) dma_a(sl1, jabs + 3, i - 4); }
+      piece(FIRST + i - 2);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -688,12 +696,18 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     // fewer tiles than CUs (N = 768 outputs: 150 tiles) because it halves the bytes staged per flop; 256x128 never won.
     // 0: 128x128x32 (4 waves, 2 blocks/CU)   2: 256x256x32 (8 waves, 1 block/CU)   4: 256x256x64 software-pipelined (K-contiguous A)
     int cfg = (M >= 256 && N >= 256) ? ((!transA || transB) ? 4 : 2) : 0;
+    if (cfg == 4 && !transA && splitk == 1) {  // 5: the same kernel with 192-row tiles, when it fills the CUs at least 10 % better
+      const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256), t192 = (long long)cdiv(M, 192) * cdiv(N, 256);
+      const long long c256 = cdiv(t256, 256) * 256, c192 = cdiv(t192, 256) * 192;
+      if (c192 * 10 <= c256 * 9) cfg = 5;
+    }
     int stg = 4;
     if (p.force_cfg >= 0) cfg = p.force_cfg & 7; else p.force_cfg = 0;
+    if (cfg == 5 && (transA || splitk != 1)) cfg = 4;
     if (cfg == 4 && transA && !transB) cfg = 2;  // (no 64-wide-K instantiation for K-strided A with K-contiguous B: unused by the step)
-    if (cfg == 4) p.ktiles = cdiv(K, 64);
+    if (cfg >= 4) p.ktiles = cdiv(K, 64);
     (void)stg;
-    const int bm = cfg == 0 ? 128 : 256, bn = cfg >= 2 ? 256 : 128;
+    const int bm = cfg == 0 ? 128 : (cfg == 5 ? 192 : 256), bn = cfg >= 2 ? 256 : 128;
     p.tiles_m = cdiv(M, bm); p.tiles_n = cdiv(N, bn);
     p.ktiles_per_split = cdiv(p.ktiles, splitk);
     p.splitk = cdiv(p.ktiles, p.ktiles_per_split);
@@ -703,7 +717,9 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
     else if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, false>), grid, dim3(512), 0, st, p);  \
     else if (cfg == 3) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, true>), grid, dim3(512), 0, st, p);   \
     else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4, false>), grid, dim3(256), 0, st, p);
-    if (cfg == 4 && transA) hipLaunchKernelGGL((gemm_bf16_k64_kernel<true, true>), grid, dim3(512), 0, st, p);
+    if (cfg == 5 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false, 192>), grid, dim3(512), 0, st, p);
+    else if (cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, true, 192>), grid, dim3(512), 0, st, p);
+    else if (cfg == 4 && transA) hipLaunchKernelGGL((gemm_bf16_k64_kernel<true, true>), grid, dim3(512), 0, st, p);
     else if (cfg == 4 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false>), grid, dim3(512), 0, st, p);
     else if (cfg == 4) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, true>), grid, dim3(512), 0, st, p);
     else if (!transA && !transB) { LAUNCH_CFG(false, false) }
