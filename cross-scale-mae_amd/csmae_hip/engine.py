@@ -350,6 +350,20 @@ class Engine:
         for i in range(c["Ne"]):
             self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te)
         latent = ws.enc["x"][c["Ne"]]
+        ce_done = None
+        if self.has_ce:
+            # the contrastive branch hangs off the encoder output only: it runs on the second stream under the decoder's GEMMs
+            # (0.3 ms of latency-bound pooling / similarity kernels that used to sit between the forward and the backward)
+            main = torch.cuda.current_stream()
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            if ops._timer is not None:
+                ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
+            else:
+                self.side.wait_stream(main)
+                ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.side.cuda_stream)
+                ce_done = torch.cuda.Event()
+                ce_done.record(self.side)
         if self.T == BF16:
             ops.cast_bf16(latent, ws.lat_lp, st=st)
             lat_op = ws.lat_lp
@@ -385,7 +399,8 @@ class Engine:
             ops.pair_loss_fwd(ke, N * Te, D, latent, (N * Te, 0, N * Te), latent, (N * Te, 0, 0), ws.e_partial, st=st)
             kw.update(e_partial=ws.e_partial, e_scale=self._pair_scale(ke, N * Te, D))
         if self.has_ce:
-            ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
+            if ce_done is not None:
+                torch.cuda.current_stream().wait_event(ce_done)
             kw.update(ce_rowloss=ws.ce_rowloss, ce_rows=B2)
         rscale = 0.5 if (self.views == 2 and c["reduction"] == "mean") else 1.0
         ops.loss_finalize(N * L, self.views, ws.rowloss, ws.mask, rscale, ws.losses, st=st, **kw)

@@ -175,6 +175,64 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, void* Cptr, f4_
   }
 }
 
+// bf16 outputs, 8 columns per lane: 16-byte stores (one instruction covers 8 rows x 128 B instead of 4).  The epilogue of a
+// 256x256 tile is bound by the store ISSUE rate of its CU, not by HBM: halving the number of store instructions is what counts.
+template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR>
+__device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
+  constexpr int LPR = FN * 16 / 8, RPP = 64 / LPR, NPASS = EROWS / RPP, NPART = WM / EROWS;
+  constexpr bool NEEDS_LOAD = EPI == EPI_DGELU;
+  static_assert(EPI != EPI_RESID, "the residual epilogue writes fp32");
+  const int col = (lane % LPR) * 8, rsub = lane / LPR;
+  const int gn = nbase + col;
+  const bool ok0 = gn < p.N, ok1 = gn + 4 < p.N;   // N % 4 == 0: a lane's 8 columns are valid as two groups of 4
+  f4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (p.bias) { if (ok0) b0 = *reinterpret_cast<const f4_t*>(p.bias + gn); if (ok1) b1 = *reinterpret_cast<const f4_t*>(p.bias + gn + 4); }
+  bf16_t* C = reinterpret_cast<bf16_t*>(Cptr);
+  bf16_t* X = reinterpret_cast<bf16_t*>(p.aux);
+  uint4 ld[NEEDS_LOAD ? NPASS : 1];
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) {
+    if (NEEDS_LOAD) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
+        const bf16_t* src = X + (long long)gm * p.ldaux + gn;
+        ld[ps] = make_uint4(0, 0, 0, 0);
+        if (ok1) ld[ps] = *reinterpret_cast<const uint4*>(src);
+        else if (ok0) { const uint2 h = *reinterpret_cast<const uint2*>(src); ld[ps].x = h.x; ld[ps].y = h.y; }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < EROWS / 16; ++ii)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = acc[part * (EROWS / 16) + ii][j];
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every load of this phase has landed, the stores below go out back to back
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int gm = mbase + part * EROWS + ps * RPP + rsub;
+      const float* src = ew + (ps * RPP + rsub) * ESTR + col;
+      f4_t v0 = *reinterpret_cast<const f4_t*>(src) + b0, v1 = *reinterpret_cast<const f4_t*>(src + 4) + b1;
+      f4_t o0 = v0, o1 = v1;
+      if (EPI == EPI_GELU) { const f4_t x0 = v0, x1 = v1; gelu_both4<bf16_t>(x0, o0, v0); gelu_both4<bf16_t>(x1, o1, v1); }
+      if (EPI == EPI_DGELU) {
+        const uint4 a = ld[ps];
+        o0 = v0 * f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+        o1 = v1 * f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
+      }
+      if (gm < p.M) {
+        if (ok1) {
+          if (EPI == EPI_GELU) *reinterpret_cast<uint4*>(X + (long long)gm * p.ldaux + gn) = make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
+          *reinterpret_cast<uint4*>(C + (long long)gm * p.ldc + gn) = make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
+        } else if (ok0) {
+          if (EPI == EPI_GELU) st4<bf16_t>(X + (long long)gm * p.ldaux + gn, v0);
+          st4<bf16_t>(C + (long long)gm * p.ldc + gn, o0);
+        }
+      }
+    }
+  }
+}
+
 template <bool TA, bool TB, int BM, int BN, int WM, int WN, int GEMM_STAGES, bool DB, int MINW = 1>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, FM = WM / 16, FN = WN / 16;
@@ -594,14 +652,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   // (no barrier: nothing has read or written the ring since the last step's barrier)
   float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
 #define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+#define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+  const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || p.ldaux % 8 == 0) && ((uintptr_t)p.aux % 16 == 0);  // 16-byte row segments
   if (p.c_dtype == CSMAE_BF16) {
-    if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
-    else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID); else EPI_CALL(bf16_t, EPI_NONE);
+    if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
+    else if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else EPI_CALL8(EPI_NONE); }
+    else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
+    else EPI_CALL(bf16_t, EPI_NONE);
   } else {
     if (p.epi == EPI_GELU) EPI_CALL(float, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(float, EPI_DGELU);
     else if (p.epi == EPI_RESID) EPI_CALL(float, EPI_RESID); else EPI_CALL(float, EPI_NONE);
   }
 #undef EPI_CALL
+#undef EPI_CALL8
 }
 
 // ------------------------------------------------------------------------------------ fp32 exact

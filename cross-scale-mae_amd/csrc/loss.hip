@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void ntx_pool_kernel(int Te, int keep, int D, 
   for (int d = threadIdx.x; d < D; d += blockDim.x) z[i * D + d] *= inv;
   if (threadIdx.x == 0) inv_norm[i] = inv;
 }
-__global__ __launch_bounds__(256) void ntx_sim_kernel(int N, int D, const float* __restrict__ z, float tau, float eps, float* __restrict__ E,
+__global__ __launch_bounds__(1024) void ntx_sim_kernel(int N, int D, const float* __restrict__ z, float tau, float eps, float* __restrict__ E,
                                                       float* __restrict__ neg, float* __restrict__ rowloss) {
   __shared__ float red[32];
   extern __shared__ float zi[];
@@ -244,12 +244,19 @@ __global__ __launch_bounds__(256) void ntx_sim_kernel(int N, int D, const float*
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float nsum = 0.f;
-  for (int j = w; j < B2; j += 4) {
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += zi[d] * z[(long long)j * D + d];
-    s = wave_sum(s);
-    float e = expf(s / tau);
-    if (lane == 0) { E[(long long)i * B2 + j] = e; if (j != i && j != partner) nsum += e; }
+  for (int j0 = 4 * w; j0 < B2; j0 += 4 * (blockDim.x >> 6)) {  // four rows per wave iteration: independent load chains, one pass over z_i
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = lane; d < D; d += 64) {
+      const float a = zi[d];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (j0 + u < B2) s[u] += a * z[(long long)(j0 + u) * D + d];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+      const float e = expf(wave_sum(s[u]) / tau);
+      if (lane == 0 && j < B2) { E[(long long)i * B2 + j] = e; if (j != i && j != partner) nsum += e; }
+    }
   }
   nsum = block_sum(nsum, red);
   if (threadIdx.x == 0) neg[i] = nsum;
@@ -288,7 +295,7 @@ extern "C" int csmae_ntxent_fwd(int N, int Te, int keep, int D, const float* lat
   CSMAE_REQUIRE(N > 0 && keep > 0 && keep < Te && D > 0 && D * 4 <= 64 * 1024, "csmae_ntxent_fwd: bad geometry N=%d Te=%d keep=%d D=%d", N, Te, keep, D);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ntx_pool_kernel, dim3(2 * N), dim3(256), 0, st, Te, keep, D, latent, z, inv_norm);
-  hipLaunchKernelGGL(ntx_sim_kernel, dim3(2 * N), dim3(256), D * sizeof(float), st, N, D, z, tau, eps, E, neg, rowloss);
+  hipLaunchKernelGGL(ntx_sim_kernel, dim3(2 * N), dim3(1024), D * sizeof(float), st, N, D, z, tau, eps, E, neg, rowloss);
   return csmae_check_launch("csmae_ntxent_fwd");
 }
 extern "C" int csmae_ntxent_bwd(int N, int D, const float* z, const float* inv_norm, const float* E, const float* neg, float tau, float eps,
@@ -323,7 +330,7 @@ extern "C" int csmae_latent_grad_finish(int lp_dtype, long long B2, int Te, int 
 
 // ------------------------------------------------------------------------------------------ scalar assembly
 // losses[0]=total [1]=recon orig [2]=recon crop [3]=cross-decoder [4]=contrastive [5]=latent [6]=sum(mask) orig [7]=sum(mask) crop
-__global__ __launch_bounds__(256) void finalize_kernel(long long per_view, int views, const float* __restrict__ rowloss, const float* __restrict__ mask,
+__global__ __launch_bounds__(1024) void finalize_kernel(long long per_view, int views, const float* __restrict__ rowloss, const float* __restrict__ mask,
                                                        float recon_scale, const float* __restrict__ cd_partial, float cd_scale,
                                                        const float* __restrict__ e_partial, float e_scale, const float* __restrict__ ce_rowloss,
                                                        int ce_rows, float* __restrict__ losses) {
@@ -347,6 +354,6 @@ extern "C" int csmae_loss_finalize(long long per_view, int views, const float* r
                                    const float* cd_partial, float cd_scale, const float* e_partial, float e_scale,
                                    const float* ce_rowloss, int ce_rows, float* losses, void* stream) {
   CSMAE_REQUIRE(per_view > 0 && (views == 1 || views == 2) && losses, "csmae_loss_finalize: bad args");
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, per_view, views, rowloss, mask, recon_scale, cd_partial, cd_scale, e_partial, e_scale, ce_rowloss, ce_rows, losses);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, per_view, views, rowloss, mask, recon_scale, cd_partial, cd_scale, e_partial, e_scale, ce_rowloss, ce_rows, losses);
   return csmae_check_launch("csmae_loss_finalize");
 }
