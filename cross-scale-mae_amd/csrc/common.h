@@ -147,5 +147,30 @@ template <typename T> __device__ __forceinline__ void gelu_both4(f4_t x, f4_t& h
 #pragma unroll
   for (int k = 0; k < 4; ++k) { float a, b; gelu_both<T>(x[k], a, b); h[k] = a; gp[k] = b; }
 }
+// bf16 outputs: the same formula on two-element vectors, so the multiplies and fmas become v_pk_mul_f32 / v_pk_fma_f32 (the GELU
+// epilogue of fc1 is VALU-bound: ~22 op-equivalents per element scalar, ~15 packed)
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_both2_fast(f2_t x, f2_t& h, f2_t& gp) {
+  const f2_t ax = {fabsf(x[0]), fabsf(x[1])};
+  const f2_t den = ax * 0.23164189f + 1.0f;
+  const f2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f2_t poly = t * 1.061405429f + -1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + -0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const f2_t xx = x * x * -0.72134752f;
+  const f2_t e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  const f2_t q = poly * t * e * 0.5f;
+  const f2_t phi = {x[0] >= 0.f ? 1.0f - q[0] : q[0], x[1] >= 0.f ? 1.0f - q[1] : q[1]};
+  h = x * phi;
+  gp = x * 0.39894228f * e + phi;
+}
+template <> __device__ __forceinline__ void gelu_both4<bf16_t>(f4_t x, f4_t& h, f4_t& gp) {
+  f2_t h0, g0, h1, g1;
+  gelu_both2_fast(f2_t{x[0], x[1]}, h0, g0);
+  gelu_both2_fast(f2_t{x[2], x[3]}, h1, g1);
+  h = f4_t{h0[0], h0[1], h1[0], h1[1]};
+  gp = f4_t{g0[0], g0[1], g1[0], g1[1]};
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
