@@ -30,6 +30,30 @@ __device__ __forceinline__ void stage_head(char* dst, const bf16_t* src, long lo
   }
 }
 
+// The same for several matrices at once, with every global load issued before the first LDS store.  stage_head() called three or
+// four times in a row ran ~3.5 dependent load->store iterations per matrix: ~10 exposed memory latencies (~10 of the ~18 us a
+// workgroup lives) before any arithmetic could start.
+template <int HD, int TP, int NT, int NM>
+struct HeadStager {
+  static constexpr int CH = HD / 8, IT = (TP * CH + NT - 1) / NT;
+  uint4 v[NM][IT];
+  __device__ __forceinline__ void load(int m, const bf16_t* src, long long row0, int ld, int col0, int T, int hd) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = threadIdx.x + i * NT, r = e / CH, c = e - r * CH;
+      v[m][i] = make_uint4(0, 0, 0, 0);
+      if (e < TP * CH && r < T && c * 8 < hd) v[m][i] = *reinterpret_cast<const uint4*>(src + (row0 + r) * ld + col0 + c * 8);
+    }
+  }
+  __device__ __forceinline__ void store(int m, char* dst) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = threadIdx.x + i * NT, r = e / CH, c = e - r * CH;
+      if (e < TP * CH) *reinterpret_cast<uint4*>(dst + r * AttnLds<HD>::STRIDE + c * 16) = v[m][i];
+    }
+  }
+};
+
 // K-contiguous fragment (lane (t,g): row = row0 + t, elements d = ks*32 + 8g .. +8)
 template <int HD>
 __device__ __forceinline__ s8_t frag_rows(const char* img, int row0, int ks, int t, int g) {
@@ -72,9 +96,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
   const int b = wid / H, h = wid - b * H;
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
-  stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);
-  stage_head<HD, TP>(Ks, qkv, row0, ld, D + h * hd, T, hd);
-  stage_head<HD, TP>(Vs, qkv, row0, ld, 2 * D + h * hd, T, hd);
+  {
+    HeadStager<HD, TP, 256, 3> sg;
+    sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, qkv, row0, ld, D + h * hd, T, hd); sg.load(2, qkv, row0, ld, 2 * D + h * hd, T, hd);
+    sg.store(0, Qs); sg.store(1, Ks); sg.store(2, Vs);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
   const float c2 = scale * LOG2E;
@@ -140,10 +166,12 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
   const int b = wid / H, h = wid - b * H;
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
-  stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);
-  stage_head<HD, TP>(Ks, qkv, row0, ld, D + h * hd, T, hd);
-  stage_head<HD, TP>(Vs, qkv, row0, ld, 2 * D + h * hd, T, hd);
-  stage_head<HD, TP>(Gs, dout, row0, D, h * hd, T, hd);
+  {
+    HeadStager<HD, TP, 256, 4> sg;
+    sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, qkv, row0, ld, D + h * hd, T, hd);
+    sg.load(2, qkv, row0, ld, 2 * D + h * hd, T, hd); sg.load(3, dout, row0, D, h * hd, T, hd);
+    sg.store(0, Qs); sg.store(1, Ks); sg.store(2, Vs); sg.store(3, Gs);
+  }
   for (int r = threadIdx.x; r < TP; r += blockDim.x) {
     float acc = 0.f, l2 = INFINITY;
     if (r < T) {
@@ -291,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
-  stage_head<HD, TP>(Qs, qkv, row0, ld, h * hd, T, hd);
-  stage_head<HD, TP>(Gs, dout, row0, D, h * hd, T, hd);
+  HeadStager<HD, TP, 256, 2> sg;
+  sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
   for (int e = threadIdx.x; e < TP * QS / 4; e += blockDim.x) reinterpret_cast<f4_t*>(dqa)[e] = f4_t{0.f, 0.f, 0.f, 0.f};
   for (int r = threadIdx.x; r < TP; r += blockDim.x) {
     float acc = 0.f, l2 = INFINITY;
@@ -316,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
     }
     lse2[r] = l2; dl[r] = acc;
   }
+  sg.store(0, Qs); sg.store(1, Gs);  // (after the row loop: its global loads are in flight together with the staging loads)
   const float c2 = scale * LOG2E;
   char* xw = xall + w * L::XB;              // this wave's patch
   const int nq = (T + 31) >> 5;             // query-tile pairs that hold real rows
