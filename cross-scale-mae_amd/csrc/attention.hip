@@ -302,6 +302,14 @@ __device__ __forceinline__ s8_t patch_cols_tr(const char* img, int c0, int t, in
   s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, p + 16 * HD * 2));
   return join_s4(lo, hi);
 }
+// phase timestamps of one workgroup (tuning aid, only in -DATTN_TIMING builds: tools/attn_phase_timing.py)
+#ifdef ATTN_TIMING
+__device__ unsigned long long g_attn_ts[16];
+extern "C" int csmae_debug_attn_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_ts), sizeof(g_attn_ts)); }
+#define TS(i) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_attn_ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TS(i)
+#endif
 template <int HD, int NKF>
 __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -319,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  TS(0);
   HeadStager<HD, TP, 256, 2> sg;
   sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
   for (int e = threadIdx.x; e < TP * QS / 4; e += blockDim.x) reinterpret_cast<f4_t*>(dqa)[e] = f4_t{0.f, 0.f, 0.f, 0.f};
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
     }
     lse2[r] = l2; dl[r] = acc;
   }
+  TS(1);
   sg.store(0, Qs); sg.store(1, Gs);  // (after the row loop: its global loads are in flight together with the staging loads)
   const float c2 = scale * LOG2E;
   char* xw = xall + w * L::XB;              // this wave's patch
@@ -375,7 +385,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int df = 0; df < DF; ++df) { dk[jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; dv[jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; }
+    TS(2 + 4 * sweep);
     __syncthreads();                        // (first sweep: staging visible; later sweeps: previous sweep's last dQ update done)
+    TS(3 + 4 * sweep);
     for (int s = 0; s < nq; ++s) {
       int ip = w + s; if (ip >= nq) ip -= nq;
       const int q0 = 32 * ip;
@@ -427,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
       }
       __syncthreads();                      // the rows this wave updated belong to another wave in the next step
     }
+    TS(4 + 4 * sweep);
     // dK, dV of the wave's keys
     if (active) {
 #pragma unroll
@@ -443,6 +456,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
       }
     }
   }
+  TS(10);
   for (int e = threadIdx.x; e < T * (HD / 4); e += blockDim.x) {
     const int q = e / (HD / 4), d = (e - q * (HD / 4)) * 4;
     if (d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d));
