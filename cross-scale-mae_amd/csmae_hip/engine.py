@@ -18,6 +18,7 @@ generator for the masking noise, the CPU generator for the crop box — Appendix
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -201,7 +202,7 @@ class Engine:
         self.lp_fresh = False  # (kept for callers that still set it; the mirror is tracked by version, see _refresh_lp)
         self._lp_ver = None
         self._saved = None
-        self.side, self.main = None, None
+        self.side, self.main, self.aux = None, None, None
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
 
     # ------------------------------------------------------------------ helpers
@@ -252,7 +253,7 @@ class Engine:
         gw = self.flat.G(name + ".weight")
         gw2 = gw.view(gw.shape[0], -1)
         dyv, xv = dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]]
-        if ops._timer is not None:  # per-kernel HIP-event timing (bench.py) measures on the main stream
+        if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN"):  # per-kernel HIP-event timing (bench.py) measures on the main stream
             ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, db=self.flat.G(name + ".bias"), st=self.st)
             return
         side = self.side
@@ -281,18 +282,23 @@ class Engine:
         self._side_reads.clear()
 
     # ------------------------------------------------------------------ transformer block
-    def _block_fwd(self, S, i, pre, M, Dm, H, B2, T):
-        P, st = self.flat.P, self.st
-        x_in, x_mid, x_out = S["x"][i], S["xm"][i], S["x"][i + 1]
-        stt = S["st"][i]
-        lse = S["lse"][i][: B2 * H * T]
-        ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), S["y1"][i], stt[0], stt[1], st=st)
-        ops.gemm(S["y1"][i], self.W(pre + "attn.qkv.weight"), S["qkv"][i], bias=P(pre + "attn.qkv.bias"), st=st)
-        ops.attn_fwd(S["qkv"][i], S["o"][i], lse, B2, T, H, Dm // H, st=st)
-        ops.gemm(S["o"][i], self.W(pre + "attn.proj.weight"), x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st)
-        ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), S["y2"][i], stt[2], stt[3], st=st)
-        ops.gemm(S["y2"][i], self.W(pre + "mlp.fc1.weight"), S["h"][i], bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=S["pre"][i], st=st)
-        ops.gemm(S["h"][i], self.W(pre + "mlp.fc2.weight"), x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st)
+    def _block_fwd(self, S, i, pre, M, Dm, H, B2, T, b0=0, nb=None, st=None):
+        """Samples [b0, b0 + nb) of the batch (default: all of it) on stream `st` (default: the engine's main stream)."""
+        P = self.flat.P
+        st = self.st if st is None else st
+        nb = B2 if nb is None else nb
+        r = slice(b0 * T, (b0 + nb) * T)
+        x_in, x_mid, x_out = S["x"][i][r], S["xm"][i][r], S["x"][i + 1][r]
+        stt = [a[r] for a in S["st"][i]]
+        lse = S["lse"][i][b0 * H * T: (b0 + nb) * H * T]
+        y1, qkv, o, y2, h, pre_a = S["y1"][i][r], S["qkv"][i][r], S["o"][i][r], S["y2"][i][r], S["h"][i][r], S["pre"][i][r]
+        ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], st=st)
+        ops.gemm(y1, self.W(pre + "attn.qkv.weight"), qkv, bias=P(pre + "attn.qkv.bias"), st=st)
+        ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, st=st)
+        ops.gemm(o, self.W(pre + "attn.proj.weight"), x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st)
+        ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], st=st)
+        ops.gemm(y2, self.W(pre + "mlp.fc1.weight"), h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st)
+        ops.gemm(h, self.W(pre + "mlp.fc2.weight"), x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st)
 
     def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps):
         """`lps` = the two ping-pong low-precision copies of the residual gradient; on entry and on exit lps[0] is current."""
@@ -347,35 +353,63 @@ class Engine:
         ops.patch_gather(img0, img1, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
         ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
         ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep, st=st)
-        for i in range(c["Ne"]):
-            self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te)
         latent = ws.enc["x"][c["Ne"]]
+        main = torch.cuda.current_stream()
+        two = self.views == 2 and ops._timer is None and not os.environ.get("CSMAE_FWD_ONE_STREAM")
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        if self.aux is None:
+            self.aux = torch.cuda.Stream()
         ce_done = None
-        if self.has_ce:
-            # the contrastive branch hangs off the encoder output only: it runs on the second stream under the decoder's GEMMs
-            # (0.3 ms of latency-bound pooling / similarity kernels that used to sit between the forward and the backward)
-            main = torch.cuda.current_stream()
-            if self.side is None:
-                self.side = torch.cuda.Stream()
-            if ops._timer is not None:
-                ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
+
+        def trunk(b0, nb, st, stream_obj):
+            """Encoder -> decoder -> prediction for samples [b0, b0 + nb).  Returns the event after the encoder (contrastive branch)."""
+            for i in range(c["Ne"]):
+                self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, b0, nb, st)
+            ev = None
+            if self.has_ce and ops._timer is None:
+                ev = torch.cuda.Event()
+                ev.record(stream_obj)
+            re_, rd_ = slice(b0 * Te, (b0 + nb) * Te), slice(b0 * Td, (b0 + nb) * Td)
+            if self.T == BF16:
+                ops.cast_bf16(latent[re_], ws.lat_lp[re_], st=st)
+                lat_op = ws.lat_lp[re_]
             else:
-                self.side.wait_stream(main)
-                ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.side.cuda_stream)
+                lat_op = latent[re_]
+            ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z[re_], bias=P("decoder_embed.bias"), st=st)
+            ops.unshuffle_fwd(ws.z[re_], P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore[b0:b0 + nb],
+                              ws.dec["x"][0][rd_], nb, L, keep, st=st)
+            for i in range(c["Nd"]):
+                self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, b0, nb, st)
+            ops.layernorm_fwd(ws.dec["x"][c["Nd"]][rd_], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp[rd_], ws.dn_st[0][rd_],
+                              ws.dn_st[1][rd_], y32=ws.emb32[rd_], st=st)
+            ops.gemm(ws.emb_lp[rd_], self._w_pred()[: c["P"]], ws.pred[rd_], bias=P("decoder_pred.bias"), st=st)
+            return ev
+
+        if two:
+            # The two views are independent until the losses: view 1 runs on the second stream.  Its kernels fill the CUs that view
+            # 0's partial waves, attention and LayerNorm kernels leave idle (same effect as the weight-gradient stream in backward).
+            self.side.wait_stream(main)
+            ev0 = trunk(0, N, st, main)
+            ev1 = trunk(N, N, self.side.cuda_stream, self.side)
+            if self.has_ce:
+                self.aux.wait_stream(main)  # (workspace reuse: the previous step's backward read E / zc on the main stream)
+                self.aux.wait_event(ev0)
+                self.aux.wait_event(ev1)
+                ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
                 ce_done = torch.cuda.Event()
-                ce_done.record(self.side)
-        if self.T == BF16:
-            ops.cast_bf16(latent, ws.lat_lp, st=st)
-            lat_op = ws.lat_lp
+                ce_done.record(self.aux)
+            main.wait_stream(self.side)
         else:
-            lat_op = latent
-        ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z, bias=P("decoder_embed.bias"), st=st)
-        ops.unshuffle_fwd(ws.z, P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore, ws.dec["x"][0], B2, L, keep, st=st)
-        for i in range(c["Nd"]):
-            self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td)
-        ops.layernorm_fwd(ws.dec["x"][c["Nd"]], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp, ws.dn_st[0], ws.dn_st[1], y32=ws.emb32, st=st)
-        emb_op = ws.emb_lp
-        ops.gemm(emb_op, self._w_pred()[: c["P"]], ws.pred, bias=P("decoder_pred.bias"), st=st)
+            ev0 = trunk(0, B2, st, main)
+            if self.has_ce:
+                if ev0 is None:
+                    ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
+                else:
+                    self.aux.wait_stream(main)
+                    ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
+                    ce_done = torch.cuda.Event()
+                    ce_done.record(self.aux)
         kind, npx = c["loss"], c["norm_pix"]
         mm = None
         if kind == "bce":
