@@ -162,6 +162,13 @@ def main():
         kernel = dict(name="gemm_bf16_kernel (MFMA 16x16x32, all three layouts)", launches_per_step=sum(v["launches"] for v in summ.values()),
                       ms_per_step=round(tot_ms, 3), tflops=round(tot_fl / tot_ms / 1e9, 1),
                       by_layout={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=round(v["work"] / v["ms"] / 1e9, 1)) for k, v in summ.items()})
+    traffic = None  # HBM bytes per GEMM launch from the committed PMC passes (counters cannot be read from inside this process)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        traffic = {"bytes_per_launch": int(t["gemm_bf16_mb_per_launch"] * 2 ** 20), "step_hbm_gb": t["step_hbm_gb"], "source": t["source"]}
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0:
         ips = a.batch * world * a.steps / elapsed
         ach = ips / world * GFLOP_PER_IMAGE / 1e3  # TFLOP/s per GPU
@@ -175,7 +182,7 @@ def main():
                        "headline_config": bool(scale)},
             "loss": round(final_loss, 5),
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "algorithmic_gflop_per_image": GFLOP_PER_IMAGE, "dominant_kernel": kernel},
+                         "traffic": traffic, "algorithmic_gflop_per_image": GFLOP_PER_IMAGE, "dominant_kernel": kernel},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
