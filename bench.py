@@ -159,7 +159,7 @@ def main():
         log("kernel timing pass done")
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["work"] for v in summ.values())
-        kernel = dict(name="gemm_bf16_kernel (MFMA 16x16x32, all three layouts)", launches_per_step=sum(v["launches"] for v in summ.values()),
+        kernel = dict(name="gemm_bf16_k64_kernel (MFMA 16x16x32, all three layouts; serialised on one stream for the HIP-event timing)", launches_per_step=sum(v["launches"] for v in summ.values()),
                       ms_per_step=round(tot_ms, 3), tflops=round(tot_fl / tot_ms / 1e9, 1),
                       by_layout={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=round(v["work"] / v["ms"] / 1e9, 1)) for k, v in summ.items()})
     traffic = None  # HBM bytes per GEMM launch from the committed PMC passes (counters cannot be read from inside this process)
