@@ -330,6 +330,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   TS(0);
   HeadStager<HD, TP, 256, 2> sg;
   sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
+  // K / V rows of a wave's key pair, straight from global memory.  The loads of sweep 0 go out with the staging loads above, those
+  // of the next sweep right after a sweep's first barrier: their latency (4k clk each, measured) stays off the critical path.
+  const int nkp = (T + 31) >> 5;            // key pairs that hold real rows
+  uint4 kraw[2][KS], vraw[2][KS];
+  auto load_kv = [&](int kp) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int key = 32 * kp + 16 * jj + t, col = ks * 32 + 8 * g;
+        kraw[jj][ks] = make_uint4(0, 0, 0, 0); vraw[jj][ks] = make_uint4(0, 0, 0, 0);
+        if (kp < nkp && key < T && col < hd) {
+          kraw[jj][ks] = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + D + h * hd + col);
+          vraw[jj][ks] = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + 2 * D + h * hd + col);
+        }
+      }
+  };
+  load_kv(w);
   for (int e = threadIdx.x; e < TP * QS / 4; e += blockDim.x) reinterpret_cast<f4_t*>(dqa)[e] = f4_t{0.f, 0.f, 0.f, 0.f};
   for (int r = threadIdx.x; r < TP; r += blockDim.x) {
     float acc = 0.f, l2 = INFINITY;
@@ -358,7 +376,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   const float c2 = scale * LOG2E;
   char* xw = xall + w * L::XB;              // this wave's patch
   const int nq = (T + 31) >> 5;             // query-tile pairs that hold real rows
-  const int nkp = (T + 31) >> 5;            // key pairs that hold real rows
   for (int sweep = 0; sweep * 4 < nkp; ++sweep) {
     const int kp = sweep * 4 + w;
     const bool active = kp < nkp;           // (wave-uniform) the last sweep may have fewer pairs than waves
@@ -369,14 +386,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const int key = k0 + 16 * jj + t, col = ks * 32 + 8 * g;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (active && key < T && col < hd) {
-          kv = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + D + h * hd + col);
-          vv = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + 2 * D + h * hd + col);
-        }
-        fk[jj][ks] = __builtin_bit_cast(s8_t, kv); fv[jj][ks] = __builtin_bit_cast(s8_t, vv);
-        *reinterpret_cast<uint4*>(xw + (16 * jj + t) * (HD * 2) + col * 2) = kv;
+        const int col = ks * 32 + 8 * g;
+        fk[jj][ks] = __builtin_bit_cast(s8_t, kraw[jj][ks]); fv[jj][ks] = __builtin_bit_cast(s8_t, vraw[jj][ks]);
+        *reinterpret_cast<uint4*>(xw + (16 * jj + t) * (HD * 2) + col * 2) = kraw[jj][ks];
       }
 #pragma unroll
     for (int df = 0; df < DF; ++df) kT[df] = patch_cols_tr<HD>(xw, df * 16, t, g);
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
     TS(2 + 4 * sweep);
     __syncthreads();                        // (first sweep: staging visible; later sweeps: previous sweep's last dQ update done)
     TS(3 + 4 * sweep);
+    if ((sweep + 1) * 4 < nkp) load_kv((sweep + 1) * 4 + w);
     for (int s = 0; s < nq; ++s) {
       int ip = w + s; if (ip >= nq) ip -= nq;
       const int q0 = 32 * ip;
