@@ -158,3 +158,25 @@ def test_crop_box_sampler_consumes_the_cpu_rng_like_the_reference():
     assert [list(sample_crop_box(224, (0.25, 0.75))) for _ in range(16)] == d["rrc_seed0_224"].tolist()
     torch.manual_seed(123)
     assert [list(sample_crop_box(64, (0.25, 0.75))) for _ in range(16)] == d["rrc_seed123_64"].tolist()
+
+
+def test_checkpoint_key_mapping_to_vit_and_back():
+    """the --transform_checkpoint_keys mapping of main_finetune.py:553-586 (timm path) and its inverse."""
+    import json
+    import os
+    from util.checkpoint_keys import from_vit_keys, to_vit_keys
+    man = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest.json")))
+    name = "mae_vit_base_MsLdCeCd" if "mae_vit_base_MsLdCeCd" in man else sorted(man)[0]
+    entry = man[name]
+    keys = list(entry["keys"]) if isinstance(entry, dict) and "keys" in entry else list(entry)
+    keys = [k[0] if isinstance(k, (list, tuple)) else k for k in keys]
+    sd = {k: i for i, k in enumerate(keys)}
+    vit = to_vit_keys(sd)
+    assert "pos_embed" in vit and "norm.weight" in vit and "norm.bias" in vit and "cls_token" in vit
+    assert "patch_embed.proj.weight" in vit and "patch_embed.proj.bias" in vit
+    assert vit["pos_embed"] == sd["encoder_pos_embed"] and vit["blocks.0.attn.qkv.weight"] == sd["encoder.0.attn.qkv.weight"]
+    assert not any(k.startswith(("decoder", "mask_token", "predictor", "encoder")) for k in vit)
+    n_enc = sum(1 for k in keys if k.startswith("encoder."))
+    assert sum(1 for k in vit if k.startswith("blocks.")) == n_enc
+    back = from_vit_keys(vit)
+    assert back == {k: v for k, v in sd.items() if "encoder" in k or k in ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias")}
