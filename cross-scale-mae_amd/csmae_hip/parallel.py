@@ -76,9 +76,11 @@ class GradSync:
             dist.broadcast(t, src=src, group=self.group)
 
 
-def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket: int = 4) -> List[Tuple[str, int, int]]:
+def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket: int = 4, taper: bool = False) -> List[Tuple[str, int, int]]:
     """Contiguous flat ranges in gradient-READY order (reverse registration order): tail (decoder + heads), encoder layers in
-    groups from the last to the first, then the stem (tokens, patch embed, decoder_embed)."""
+    groups from the last to the first, then the stem (tokens, patch embed, decoder_embed).  With `taper` the groups shrink
+    towards the end of the backward pass (…, 4, 2, 1, 1): whatever is reduced after the last backward kernel is exposed time, so
+    the final messages should be small (one ViT-B layer = 28 MB fp32 ~ 0.3 ms on the ring) while the early ones stay large."""
     def start(prefix):
         for n in names:
             if n.startswith(prefix):
@@ -92,7 +94,10 @@ def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket:
     hi = dec0
     i = n_encoder
     while i > 0:
-        j = max(0, i - enc_per_bucket)
+        size = enc_per_bucket
+        if taper:
+            size = 1 if i <= 2 else (2 if i <= 4 else enc_per_bucket)
+        j = max(0, i - size)
         lo = start(f"encoder.{j}.")
         out.append((("enc", j), lo, hi))  # final once encoder layer j's backward has been enqueued
         hi, i = lo, j
@@ -118,7 +123,7 @@ class DataParallel(torch.nn.Module):
             # rank-0 parameters and buffers win (DDP constructor semantics, main_pretrain.py:418-420)
             self._sync.broadcast([flat.p] + [b for b in self.module.buffers()])
             n_enc = len(self.module.encoder)
-            self._ranges = {name: (lo, hi) for name, lo, hi in bucket_ranges(flat.slots, flat.names, n_enc)}
+            self._ranges = {name: (lo, hi) for name, lo, hi in bucket_ranges(flat.slots, flat.names, n_enc, taper=True)}
         return self._sync
 
     # called by Engine.backward

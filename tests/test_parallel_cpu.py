@@ -43,6 +43,10 @@ def _worker(rank, world, port, q):
         assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
         assert [r[0] for r in ranges[1:-1]] == [("enc", 2), ("enc", 0)]
         assert ranges[0][1] == slots["decoder.0.norm1.weight"][0] and ranges[-1][2] == slots["encoder.0.norm1.weight"][0]
+        tap = bucket_ranges(slots, names, n_encoder=6, enc_per_bucket=4, taper=True)  # small messages last: groups 4, 1, 1 (12 layers: 4, 4, 2, 1, 1)
+        assert [r[0] for r in tap[1:-1]] == [("enc", 2), ("enc", 1), ("enc", 0)]
+        cov = sorted((lo, hi) for _, lo, hi in tap)
+        assert cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
         # mean all-reduce of every range == mean of the per-rank gradients
         g = torch.Generator().manual_seed(100 + rank)
         flat = torch.randn(total, generator=g)
