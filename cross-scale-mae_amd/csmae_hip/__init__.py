@@ -47,6 +47,7 @@ _SIGNATURES = {
     "csmae_ntxent_bwd": [I, I, P, P, P, P, F, F, P, P, P],
     "csmae_latent_grad_finish": [I, L, I, I, P, P, F, P, P],
     "csmae_loss_finalize": [L, I, P, P, F, P, F, P, F, P, I, P, P],
+    "csmae_augment_u8": [L, I, I, I, I, P, P, P, P, P, P],
     "csmae_adamw": [L, P, P, P, P, P, P, P, F, F, F, F, F, F, P, P],
     "csmae_cast_f32_to_bf16": [L, P, P, P],
     "csmae_colsum": [I, L, I, P, L, P, P],

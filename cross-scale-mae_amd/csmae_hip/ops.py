@@ -225,6 +225,14 @@ def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps, step, 
           "csmae_adamw")
 
 
+def augment_u8(src, meta, mean, inv_std, dst, st=None):
+    """src [N, Hmax, Wmax, C] uint8, meta [N, 8] int32 {H, W, i, j, h, w, hflip, vflip}, dst [N, C, S, S] fp32 (util/datasets.py:120-136)."""
+    N, Hmax, Wmax, C = src.shape
+    assert src.dtype == torch.uint8 and src.is_contiguous() and meta.dtype == torch.int32 and meta.shape == (N, 8) and dst.shape[:2] == (N, C)
+    check(load().csmae_augment_u8(N, C, Hmax, Wmax, dst.shape[-1], _p(src), _p(meta), _p(mean), _p(inv_std), _p(dst),
+                                  st if st is not None else stream()), "csmae_augment_u8")
+
+
 def cast_bf16(src, dst, st=None):
     check(load().csmae_cast_f32_to_bf16(src.numel(), _p(src), _p(dst), st if st is not None else stream()), "csmae_cast_f32_to_bf16")
 

@@ -242,3 +242,76 @@ extern "C" int csmae_rows_scatter_add(int dtype, long long rows, int D, const vo
   else { csmae_set_error("csmae_rows_scatter_add: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_rows_scatter_add");
 }
+
+// ------------------------------------------------------------------------------------------ input step
+// The reference's training transform (util/datasets.py:120-136) on the GPU, one kernel per batch of decoded uint8 images:
+//   ToTensor (u8 / 255) -> Normalize(mean, std) -> RandomHorizontalFlip -> RandomVerticalFlip ->
+//   RandomResizedCrop(S, scale (0.25, 1), bicubic, antialias)
+// The random decisions are drawn on the host (torchvision's RNG order) and arrive as `meta[n] = {H, W, i, j, h, w, hflip, vflip}`;
+// `src` is [N, Hmax, Wmax, C] uint8 (HWC, each image in the top-left H x W corner), `dst` [N, C, S, S] fp32.
+// Resampling follows ATen's separable anti-aliased bicubic (a = -0.5; support = 2 * max(scale, 1); weights renormalised).
+__device__ __forceinline__ float cubic_aa(float x) {
+  x = fabsf(x);
+  const float a = -0.5f;
+  if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+  if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+  return 0.f;
+}
+#define AUG_MAX_TAPS 96
+__global__ __launch_bounds__(256) void augment_u8_kernel(int C, int Hmax, int Wmax, int S, const unsigned char* __restrict__ src,
+                                                         const int* __restrict__ meta, const float* __restrict__ mean,
+                                                         const float* __restrict__ inv_std, float* __restrict__ dst) {
+  __shared__ float wy[AUG_MAX_TAPS];
+  __shared__ int ylo_s, yn_s;
+  const long long n = blockIdx.x;
+  const int oy = blockIdx.y;
+  const int* mt = meta + n * 8;
+  const int H = mt[0], W = mt[1], bi = mt[2], bj = mt[3], bh = mt[4], bw = mt[5], hf = mt[6], vf = mt[7];
+  const float sy = (float)bh / (float)S, sx = (float)bw / (float)S;
+  const float supy = sy >= 1.f ? 2.f * sy : 2.f, invy = sy >= 1.f ? 1.f / sy : 1.f;
+  const float supx = sx >= 1.f ? 2.f * sx : 2.f, invx = sx >= 1.f ? 1.f / sx : 1.f;
+  if (threadIdx.x == 0) {
+    const float cy = sy * (oy + 0.5f);
+    int lo = (int)(cy - supy + 0.5f); lo = lo < 0 ? 0 : lo;
+    int hi = (int)(cy + supy + 0.5f); hi = hi > bh ? bh : hi;
+    int nn = hi - lo; nn = nn > AUG_MAX_TAPS ? AUG_MAX_TAPS : nn;
+    float tot = 0.f;
+    for (int k = 0; k < nn; ++k) { const float w = cubic_aa((k + lo - cy + 0.5f) * invy); wy[k] = w; tot += w; }
+    for (int k = 0; k < nn; ++k) wy[k] /= tot;
+    ylo_s = lo; yn_s = nn;
+  }
+  __syncthreads();
+  const int ylo = ylo_s, yn = yn_s;
+  const unsigned char* img = src + n * (long long)Hmax * Wmax * C;
+  for (int ox = threadIdx.x; ox < S; ox += blockDim.x) {
+    const float cx = sx * (ox + 0.5f);
+    int xlo = (int)(cx - supx + 0.5f); xlo = xlo < 0 ? 0 : xlo;
+    int xhi = (int)(cx + supx + 0.5f); xhi = xhi > bw ? bw : xhi;
+    int xn = xhi - xlo; xn = xn > AUG_MAX_TAPS ? AUG_MAX_TAPS : xn;
+    float totx = 0.f;
+    for (int b = 0; b < xn; ++b) totx += cubic_aa((b + xlo - cx + 0.5f) * invx);
+    const float rtx = 1.f / totx;
+    for (int c = 0; c < C; ++c) {
+      const float mu = mean[c], is = inv_std[c];
+      float acc = 0.f;
+      for (int a = 0; a < yn; ++a) {
+        int yy = bi + ylo + a; yy = vf ? H - 1 - yy : yy;          // row of the flipped image -> row of the stored image
+        const unsigned char* rowp = img + ((long long)yy * Wmax) * C + c;
+        float hsum = 0.f;
+        for (int b = 0; b < xn; ++b) {
+          int xx = bj + xlo + b; xx = hf ? W - 1 - xx : xx;
+          const float v = ((float)rowp[(long long)xx * C] * (1.f / 255.f) - mu) * is;
+          hsum += cubic_aa((b + xlo - cx + 0.5f) * invx) * rtx * v;
+        }
+        acc += wy[a] * hsum;
+      }
+      dst[((n * C + c) * S + oy) * (long long)S + ox] = acc;
+    }
+  }
+}
+extern "C" int csmae_augment_u8(long long N, int C, int Hmax, int Wmax, int S, const unsigned char* src, const int* meta, const float* mean,
+                                const float* inv_std, float* dst, void* stream) {
+  CSMAE_REQUIRE(N > 0 && C > 0 && Hmax > 0 && Wmax > 0 && S > 0 && src && meta && mean && inv_std && dst, "csmae_augment_u8: bad arguments");
+  hipLaunchKernelGGL(augment_u8_kernel, dim3((unsigned)N, (unsigned)S), dim3(256), 0, (hipStream_t)stream, C, Hmax, Wmax, S, src, meta, mean, inv_std, dst);
+  return csmae_check_launch("csmae_augment_u8");
+}

@@ -127,15 +127,29 @@ def main(args):
     torch.manual_seed(seed)
     np.random.seed(seed)
 
-    if args.dataset_type != "synthetic":
-        raise NotImplementedError(f"--dataset_type {args.dataset_type}: the reference's dataset readers (util/datasets.py) depend on rasterio / fiona / "
-                                  "torchvision and are outside the MI355X hot-path scope; use --dataset_type synthetic or pass your own "
+    if args.dataset_type not in ("synthetic", "fmow_rgb"):
+        raise NotImplementedError(f"--dataset_type {args.dataset_type}: the reference's multi-band readers (util/datasets.py) depend on rasterio / fiona "
+                                  "and are outside the MI355X hot-path scope; use --dataset_type synthetic / fmow_rgb or pass your own "
                                   "iterable of (samples, _) to engine_pretrain.train_one_epoch")
     channels = args.input_channels or 3
     if device.type == "cuda":
         torch.cuda.set_device(getattr(args, "gpu", 0) if args.distributed else torch.cuda.current_device())
         device = torch.device("cuda", torch.cuda.current_device())
-    data_loader_train = SyntheticLoader(args.batch_size, channels, args.input_size, args.synthetic_len, device, seed)
+    if args.dataset_type == "synthetic":
+        data_loader_train = SyntheticLoader(args.batch_size, channels, args.input_size, args.synthetic_len, device, seed)
+    else:
+        # fMoW-RGB CSV (util/datasets.py:161-206): the workers only decode; flips, normalisation and the bicubic RandomResizedCrop of
+        # the reference's transform (util/datasets.py:120-136) run in one HIP kernel behind pinned double-buffered uint8 staging
+        from util.gpu_input import CsvImageDataset, GpuAugment, PrefetchLoader, collate_uint8
+        dataset = CsvImageDataset(args.train_path)
+        if args.distributed:
+            sampler = torch.utils.data.DistributedSampler(dataset, num_replicas=misc.get_world_size(), rank=misc.get_rank(), shuffle=True)
+        else:
+            sampler = torch.utils.data.RandomSampler(dataset)
+        raw = torch.utils.data.DataLoader(dataset, sampler=sampler, batch_size=args.batch_size, num_workers=args.num_workers,
+                                          pin_memory=False, drop_last=True, collate_fn=collate_uint8)
+        data_loader_train = PrefetchLoader(raw, GpuAugment(args.input_size, device=device))
+        data_loader_train.sampler = sampler
 
     kwargs = dict(vars(args))
     if args.input_channels is None:

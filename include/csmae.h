@@ -124,6 +124,13 @@ int csmae_loss_finalize(long long per_view, int views, const float* rowloss, con
                         const float* cd_partial, float cd_scale, const float* e_partial, float e_scale,
                         const float* ce_rowloss, int ce_rows, float* losses, void* stream);
 
+/* ---- input step before the path (util/datasets.py:120-136 training transform): decoded uint8 HWC images ->
+ * ToTensor, Normalize(mean, std), horizontal / vertical flip, RandomResizedCrop(S, bicubic, antialias) in one kernel.
+ * src [N, Hmax, Wmax, C] u8 (image n in the top-left H x W corner), meta [N, 8] int32 = {H, W, i, j, h, w, hflip, vflip}
+ * (box in the coordinates of the flipped image; drawn on the host in torchvision's RNG order), dst [N, C, S, S] fp32. */
+int csmae_augment_u8(long long N, int C, int Hmax, int Wmax, int S, const unsigned char* src, const int* meta, const float* mean,
+                     const float* inv_std, float* dst, void* stream);
+
 /* ---- optimizer side (main_pretrain.py:426-427 torch.optim.AdamW; util/misc.py:314 backward products) */
 int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
                 float* m, float* v, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,

@@ -323,3 +323,20 @@ def train_step(sd, cfg, imgs, noise_orig, noise_crop, box, opt: torch.optim.Opti
     out["loss"].backward()
     opt.step()
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------- input step
+def train_transform(img_u8, params, mean, std, S):
+    """Reference training transform on one decoded image (util/datasets.py:120-136) with the random decisions given:
+    ToTensor -> Normalize -> hflip -> vflip -> resized_crop(bicubic, antialias).  img_u8 [H, W, C] uint8 -> [C, S, S] float32.
+    `params` = (H, W, i, j, h, w, hflip, vflip), the box in the coordinates of the flipped image (torchvision F.resized_crop)."""
+    import torch.nn.functional as F
+    H, W, i, j, h, w, hf, vf = [int(v) for v in params]
+    x = torch.as_tensor(img_u8)[:H, :W].permute(2, 0, 1).to(torch.float32) / 255.0
+    x = (x - torch.tensor(mean, dtype=torch.float32)[:, None, None]) / torch.tensor(std, dtype=torch.float32)[:, None, None]
+    if hf:
+        x = x.flip(-1)
+    if vf:
+        x = x.flip(-2)
+    x = x[:, i:i + h, j:j + w]
+    return F.interpolate(x[None], size=(S, S), mode="bicubic", align_corners=False, antialias=True)[0]

