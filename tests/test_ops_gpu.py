@@ -128,7 +128,8 @@ def test_gemm_rejects_bad_args(ops):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-ATT = [(3, 50, 2, 64), (2, 197, 2, 32), (2, 17, 3, 32), (2, 5, 2, 64), (1, 65, 2, 80), (1, 257, 1, 32), (2, 33, 2, 16), (1, 224, 1, 64)]
+ATT = [(3, 50, 2, 64), (2, 197, 2, 32), (2, 17, 3, 32), (2, 5, 2, 64), (1, 65, 2, 80), (1, 257, 1, 32), (2, 33, 2, 16), (1, 224, 1, 64),
+       (1, 129, 2, 32), (1, 97, 1, 64), (2, 96, 2, 32), (1, 160, 1, 32)]  # single-pass backward: 5 / 4 / 3 / 5 key pairs over 4 waves
 
 
 @pytest.mark.parametrize("geom", ATT)
