@@ -441,6 +441,60 @@ class Engine:
         self._saved = dict(img0=img0, img1=img1, N=N, keep=keep, mm=mm, rscale=rscale)
         return ws
 
+    # ------------------------------------------------------------------ stand-alone halves (inference, one view)
+    def encode(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor):
+        """`forward_encoder` of the reference (MAE_ViT_Baseline.py:243-266) for a single-view engine: patch-embed the kept patches,
+        pos-embed, cls, encoder blocks (encoder_norm's output is discarded there).  -> latent [N, keep+1, D], mask, ids_restore."""
+        assert self.views == 1, "encode()/decode() run on a single-view (Baseline-variant) engine"
+        c = self.cfg
+        N = imgs.shape[0]
+        keep = int(c["L"] * (1 - mask_ratio))
+        if keep < 1:
+            raise ValueError(f"mask_ratio={mask_ratio} keeps no patch (L={c['L']})")
+        if self.ws is None or self.ws.N != N or self.ws.keep != keep:
+            self.ws = None
+            self.ws = Workspace(self, N, keep)
+        ws, P = self.ws, self.flat.P
+        self.st = st = ops.stream()
+        L, D = c["L"], c["D"]
+        self._refresh_lp()
+        ws.noise.copy_(noise)
+        ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
+        ops.patch_gather(imgs, None, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
+        ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
+        ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], N, keep, st=st)
+        for i in range(c["Ne"]):
+            self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], N, ws.Te)
+        return ws.enc["x"][c["Ne"]].view(N, ws.Te, D).clone(), ws.mask.clone(), ws.ids_restore.clone()
+
+    def decode(self, latent: torch.Tensor, ids_restore: torch.Tensor):
+        """`forward_decoder` (MAE_ViT_Baseline.py:268-297): decoder_embed, mask-token fill + unshuffle + pos-embed, decoder blocks,
+        decoder_norm, decoder_pred.  -> pred [N, L, P] (cls dropped), x_embed [N, L+1, Dd] (post-norm, cls included)."""
+        assert self.views == 1
+        c = self.cfg
+        N, Te, D = latent.shape
+        keep, L, Dd = Te - 1, c["L"], c["Dd"]
+        if self.ws is None or self.ws.N != N or self.ws.keep != keep:
+            self.ws = None
+            self.ws = Workspace(self, N, keep)
+        ws, P = self.ws, self.flat.P
+        self.st = st = ops.stream()
+        self._refresh_lp()
+        lat = latent.reshape(N * Te, D).to(torch.float32).contiguous()
+        if self.T == BF16:
+            ops.cast_bf16(lat, ws.lat_lp, st=st)
+            lat_op = ws.lat_lp
+        else:
+            lat_op = lat
+        ws.ids_restore.copy_(ids_restore)
+        ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z, bias=P("decoder_embed.bias"), st=st)
+        ops.unshuffle_fwd(ws.z, P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore, ws.dec["x"][0], N, L, keep, st=st)
+        for i in range(c["Nd"]):
+            self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], N, ws.Td)
+        ops.layernorm_fwd(ws.dec["x"][c["Nd"]], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp, ws.dn_st[0], ws.dn_st[1], y32=ws.emb32, st=st)
+        ops.gemm(ws.emb_lp, self._w_pred()[: c["P"]], ws.pred, bias=P("decoder_pred.bias"), st=st)
+        return ws.pred.view(N, ws.Td, c["P"])[:, 1:, :].clone(), ws.emb32.view(N, ws.Td, Dd).clone()
+
     @staticmethod
     def _pair_scale(kind, rows, D):
         return 1.0 / (rows * D) if kind in ("mse", "mae") else 1.0 / rows

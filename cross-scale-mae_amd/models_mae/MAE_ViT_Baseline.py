@@ -173,8 +173,52 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
         loss, pred, mask, enc, dec = self._run(imgs, mask_ratio, noise, box)
         return (loss, pred, mask) if not return_embeds else (loss, pred, mask, enc, dec)
 
-    def forward_encoder(self, x, mask_ratio):
-        raise NotImplementedError("stand-alone forward_encoder is not exposed on the MI355X path; call the model (return_embeds=True)")
+    def _engine_single(self, x):
+        """Single-view inference engine over the same flat parameters (stand-alone forward_encoder / forward_decoder)."""
+        from csmae_hip.engine import Engine
+        eng = self._engine(x)
+        dt_ = self.compute_dtype if self.compute_dtype is not None else (torch.bfloat16 if torch.is_autocast_enabled() else torch.float32)
+        cache = self.__dict__.setdefault("_single_engines", {})
+        key = (id(eng.flat), dt_)
+        if key not in cache:
+            cfg = dict(eng.cfg)
+            cfg["variant"] = "Baseline"
+            cache.clear()
+            cache[key] = Engine(self, eng.flat, cfg, dt_)
+        return cache[key]
 
+    @torch.no_grad()
+    def forward_encoder(self, x, mask_ratio):
+        """(latent [N, keep+1, D], mask [N, L], ids_restore [N, L]) — MAE_ViT_Baseline.py:243-266.  Inference only (no autograd
+        graph): training goes through `forward`, whose backward is one hand-written pass."""
+        x = x.contiguous().float()
+        noise = torch.rand(x.shape[0], self.num_patches, device=x.device)  # MAE_ViT_Shared.py:66
+        return self._engine_single(x).encode(x, mask_ratio, noise)
+
+    @torch.no_grad()
     def forward_decoder(self, x, ids_restore):
-        raise NotImplementedError("stand-alone forward_decoder is not exposed on the MI355X path; call the model (return_embeds=True)")
+        """(pred [N, L, p*p*C], x_embed [N, L+1, Dd]) — MAE_ViT_Baseline.py:268-297.  Inference only."""
+        return self._engine_single(x).decode(x, ids_restore)
+
+    @torch.no_grad()
+    def forward_loss(self, imgs, pred, mask=None):
+        """Reconstruction loss of `--loss` on patchified `imgs` (MAE_ViT_Shared.py:269-290) through the same fused HIP loss kernels
+        `forward` uses (image read once, patchify / norm_pix / bce scaling inside the kernel).  Inference only."""
+        from csmae_hip import ops
+        N, L, P = pred.shape
+        C, S, p = self.input_channels, self.input_size, self.patch_size
+        imgs = imgs.contiguous().float()
+        dev = imgs.device
+        full = torch.zeros(N, L + 1, P, device=dev, dtype=torch.float32)  # the kernels index predictions with the cls row in place
+        full[:, 1:, :] = pred
+        full = full.view(N * (L + 1), P)
+        rowloss = torch.empty(N * L, device=dev, dtype=torch.float32)
+        mm = None
+        if self.loss == "bce":
+            mm = torch.empty(2, device=dev, dtype=torch.float32)
+            ops.target_minmax(imgs, None, torch.empty(N * L * 2, device=dev, dtype=torch.float32), mm, N, N, C, S, p, self.norm_pix_loss)
+        ops.recon_loss_fwd(self.loss, self.norm_pix_loss, imgs, None, full, mm, rowloss, N, N, C, S, p)
+        m = torch.ones(N, L, device=dev, dtype=torch.float32) if mask is None else mask.to(torch.float32).contiguous()
+        losses = torch.zeros(8, device=dev, dtype=torch.float32)
+        ops.loss_finalize(N * L, 1, rowloss, m, 1.0, losses)
+        return losses[1].clone()

@@ -286,3 +286,35 @@ def test_api_behaviour():
         ce(x)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(x.cpu())
+
+
+def test_standalone_encoder_decoder_loss_match_oracle():
+    """forward_encoder / forward_decoder / forward_loss stay callable on their own (inference), against the oracle's
+    encoder / decoder / loss on the same weights, noise and images."""
+    import csmae_oracle as O
+    import models_mae
+    torch.manual_seed(0)
+    micro = dict(dim_model=128, encoder_num_layers=2, encoder_num_heads=2, decoder_embed_dim=64, decoder_num_layers=2, decoder_num_heads=2)
+    m = models_mae.MAE_ViT_MsLdCeCd(**micro, input_size=64, predictor_hidden_size=128).cuda().eval()
+    imgs = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    cfg = O.make_cfg(input_size=64, patch_size=16, variant="Baseline", dim_model=128, encoder_num_layers=2, encoder_num_heads=2, decoder_embed_dim=64,
+                     decoder_num_layers=2, decoder_num_heads=2)
+    torch.manual_seed(7)
+    latent, mask, ids_restore = m.forward_encoder(imgs, 0.75)
+    torch.manual_seed(7)
+    noise = torch.rand(3, 16, device="cuda").cpu()   # the draw forward_encoder made (MAE_ViT_Shared.py:66)
+    lat_o, mask_o, ids_o = O.encoder(sd, cfg, imgs.cpu(), noise, 0.75)
+    assert torch.equal(ids_restore.cpu(), ids_o) and torch.equal(mask.cpu(), mask_o)
+    assert torch.allclose(latent.cpu(), lat_o, atol=2e-4, rtol=1e-4), float((latent.cpu() - lat_o).abs().max())
+    pred, emb = m.forward_decoder(latent, ids_restore)
+    pred_o, emb_o = O.decoder(sd, cfg, lat_o, ids_o)
+    assert pred.shape == pred_o.shape and emb.shape == emb_o.shape
+    assert torch.allclose(pred.cpu(), pred_o, atol=3e-4, rtol=1e-4) and torch.allclose(emb.cpu(), emb_o, atol=3e-4, rtol=1e-4)
+    loss = m.forward_loss(imgs, pred, mask)
+    want = O.loss_fn("mse", O.recon_target(imgs.cpu(), 16, 3, False), pred_o, mask_o)
+    assert abs(float(loss) - float(want)) <= 1e-4 * abs(float(want)), (float(loss), float(want))
+    # the training entry point is unaffected by the stand-alone calls
+    m.train()
+    out = m(imgs, mask_ratio=0.75)
+    assert torch.isfinite(out[0])
