@@ -318,3 +318,27 @@ def test_standalone_encoder_decoder_loss_match_oracle():
     m.train()
     out = m(imgs, mask_ratio=0.75)
     assert torch.isfinite(out[0])
+
+
+@pytest.mark.parametrize("name,kw,n", [("mae_vit_large_MsLdCeCd", dict(input_size=256, patch_size="16", input_channels=4), 2),
+                                       ("mae_vit_huge_MsLdCeCd", dict(input_size=224, patch_size="14"), 2)])
+def test_large_and_huge_presets_one_step(name, kw, n):
+    """BASELINE.json configs 4 / 5 geometries (4-band 256^2 ViT-L; ViT-H/14: hd = 80, P = 588 not a multiple of 8) through the
+    throughput kernels: finite gradients, bf16 loss within 2e-2 of the fp32 engine, one fused AdamW step."""
+    import models_mae
+    from csmae_hip.optim import FusedAdamW, add_weight_decay
+    torch.manual_seed(0)
+    m = models_mae.__dict__[name](**kw).cuda().train()
+    x = torch.randn(n, kw.get("input_channels", 3), kw["input_size"], kw["input_size"], device="cuda")
+    losses = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m.compute_dtype = dt
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(1)
+        loss, pred, mask = m(x, mask_ratio=0.75)
+        loss.backward()
+        assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+        losses[dt] = float(loss.detach())
+    FusedAdamW(add_weight_decay(m, 0.05), lr=1e-4, betas=(0.9, 0.95)).step()
+    torch.cuda.synchronize()
+    assert abs(losses[torch.bfloat16] - losses[torch.float32]) <= 2e-2 * abs(losses[torch.float32]), losses
