@@ -203,6 +203,7 @@ class Engine:
         self._lp_ver = None
         self._saved = None
         self.side, self.main, self.aux = None, None, None
+        self._fwd_streams = []
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
 
     # ------------------------------------------------------------------ helpers
@@ -389,17 +390,27 @@ class Engine:
         if two:
             # The two views are independent until the losses: view 1 runs on the second stream.  Its kernels fill the CUs that view
             # 0's partial waves, attention and LayerNorm kernels leave idle (same effect as the weight-gradient stream in backward).
-            self.side.wait_stream(main)
-            ev0 = trunk(0, N, st, main)
-            ev1 = trunk(N, N, self.side.cuda_stream, self.side)
+            nch = int(os.environ.get("CSMAE_FWD_CHUNKS", "2"))  # tuning aid: independent sample chunks in flight (2 = one per view)
+            if nch < 2 or B2 % nch:
+                nch = 2
+            while len(self._fwd_streams) < nch - 1:
+                self._fwd_streams.append(self.side if not self._fwd_streams else torch.cuda.Stream())
+            per = B2 // nch
+            for so in self._fwd_streams[: nch - 1]:
+                so.wait_stream(main)         # (the stem; and the previous step's readers of the workspace)
+            evs = [trunk(0, per, st, main)]
+            for k in range(1, nch):
+                so = self._fwd_streams[k - 1]
+                evs.append(trunk(k * per, per, so.cuda_stream, so))
             if self.has_ce:
                 self.aux.wait_stream(main)  # (workspace reuse: the previous step's backward read E / zc on the main stream)
-                self.aux.wait_event(ev0)
-                self.aux.wait_event(ev1)
+                for ev in evs:
+                    self.aux.wait_event(ev)
                 ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
                 ce_done = torch.cuda.Event()
                 ce_done.record(self.aux)
-            main.wait_stream(self.side)
+            for so in self._fwd_streams[: nch - 1]:
+                main.wait_stream(so)
         else:
             ev0 = trunk(0, B2, st, main)
             if self.has_ce:
