@@ -833,7 +833,7 @@ extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, c
   const bool k64 = dtype == CSMAE_BF16 && tile == 256 && (g_force_cfg < 0 || (g_force_cfg & 7) == 4);  // same choice as csmae_gemm
   const int kt = dtype == CSMAE_BF16 ? (k64 ? 64 : GEMM_BK) : 16;
   const long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile), ktiles = cdiv(K, kt);
-  static const int slots256 = getenv("CSMAE_DW_SLOTS") ? atoi(getenv("CSMAE_DW_SLOTS")) : 128;  // blocks per weight-gradient GEMM (tuning aid). Half the CUs: the other half runs the main stream, and the slab traffic halves
+  static const int slots256 = getenv("CSMAE_DW_SLOTS") ? atoi(getenv("CSMAE_DW_SLOTS")) : 160;  // blocks per weight-gradient GEMM (tuning aid): ~5/8 of the CUs — the rest runs the main stream — and fewer fp32 slabs than a full-chip split (flat optimum 128..192)
   const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? slots256 : 512) : 2048;
   long long S = slots / tiles;
   if (S > ktiles / (k64 ? 4 : 6)) S = ktiles / (k64 ? 4 : 6);
