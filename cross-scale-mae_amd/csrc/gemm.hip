@@ -451,6 +451,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_ke
 // (all 160 KiB), one unit = one operand's [256 x 64] image; a K step consumes units (2j, 2j+1) while 2j+2 .. 2j+4 are in flight.
 //   K-contiguous image: [256 rows][64 k], 128-B rows, 16-B chunk swizzle c ^ (row & 7) (conflict-free ds_read_b128)
 //   K-strided image   : two [32 k][256] images of the 32-wide kernel back to back (ds_read_b64_tr_b16)
+// phase timestamps of one workgroup (tuning aid, only in -DGEMM_TIMING builds: tools/gemm_phase_timing.py)
+#ifdef GEMM_TIMING
+__device__ unsigned long long g_gemm_ts[8];
+extern "C" int csmae_debug_gemm_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_ts), sizeof(g_gemm_ts)); }
+#define GTS(i) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_gemm_ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GTS(i)
+#endif
 template <bool TA, bool TB, int BM = 256>  // BM = 192 (K-contiguous A only): 6 instead of 8 A fragments per wave, for outputs whose 256-row
 __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  // tiling leaves too many CUs idle (N = 768: 150 -> 201 tiles)
   static_assert(BM == 256 || (BM == 192 && !TA), "192-row tiles exist for K-contiguous A only");
@@ -470,6 +478,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
   void* Cptr = p.epi == EPI_SPLIT ? static_cast<void*>(reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride) : p.C;
 
+  GTS(0);
   const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   const unsigned kstepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
   const unsigned kstepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
@@ -580,6 +589,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPA + PPU) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  GTS(1);
   s8_t fa[FM], fb0[FN], fb1[FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i) read_a(0, 0, i, fa[i]);
@@ -629,6 +639,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   if (nsteps >= 3) { step(kt_begin + j, sl, std::integral_constant<int, 1>{}); ++j; sl = nxt(sl, 2); }
   if (nsteps >= 2) { step(kt_begin + j, sl, std::integral_constant<int, 2>{}); ++j; sl = nxt(sl, 2); }
   step(kt_begin + j, sl, std::integral_constant<int, 3>{});
+  GTS(2);
   if (TA && TB && do_cs) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -665,6 +676,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   }
 #undef EPI_CALL
 #undef EPI_CALL8
+  GTS(3);
 }
 
 // ------------------------------------------------------------------------------------ fp32 exact
