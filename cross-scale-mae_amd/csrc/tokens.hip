@@ -258,10 +258,20 @@ __device__ __forceinline__ float cubic_aa(float x) {
   return 0.f;
 }
 #define AUG_MAX_TAPS 96
-__global__ __launch_bounds__(256) void augment_u8_kernel(int C, int Hmax, int Wmax, int S, const unsigned char* __restrict__ src,
+#define AUG_MAX_C 8
+#define AUG_WX_TAPS 24   // horizontal weights kept in LDS (24 KiB: several workgroups per CU); taps beyond are recomputed (scale > 5.5)
+// One workgroup per (image, output row).  The normalised vertical weights live in LDS, each thread (output column) keeps its
+// normalised horizontal weights in LDS too (column-major: conflict-free), so the tap loop is one byte load + convert + fma per
+// channel.  Normalisation is applied once at the end: sum_k w_k (v_k / 255 - mean) / std = (sum_k w_k v_k) / (255 std) - mean / std
+// because the weights sum to one.
+template <int CT>  // CT = channel count known at compile time (3, 4) or 0 = any C <= 8
+__global__ __launch_bounds__(256) void augment_u8_kernel(int Crt, int Hmax, int Wmax, int S, const unsigned char* __restrict__ src,
                                                          const int* __restrict__ meta, const float* __restrict__ mean,
                                                          const float* __restrict__ inv_std, float* __restrict__ dst) {
   __shared__ float wy[AUG_MAX_TAPS];
+  __shared__ float wx[AUG_WX_TAPS][256];
+  const int C = CT ? CT : Crt;
+  constexpr int NC = CT ? CT : AUG_MAX_C;
   __shared__ int ylo_s, yn_s;
   const long long n = blockIdx.x;
   const int oy = blockIdx.y;
@@ -283,35 +293,43 @@ __global__ __launch_bounds__(256) void augment_u8_kernel(int C, int Hmax, int Wm
   __syncthreads();
   const int ylo = ylo_s, yn = yn_s;
   const unsigned char* img = src + n * (long long)Hmax * Wmax * C;
-  for (int ox = threadIdx.x; ox < S; ox += blockDim.x) {
+  const int tid = threadIdx.x;
+  for (int ox = tid; ox < S; ox += blockDim.x) {
     const float cx = sx * (ox + 0.5f);
     int xlo = (int)(cx - supx + 0.5f); xlo = xlo < 0 ? 0 : xlo;
     int xhi = (int)(cx + supx + 0.5f); xhi = xhi > bw ? bw : xhi;
     int xn = xhi - xlo; xn = xn > AUG_MAX_TAPS ? AUG_MAX_TAPS : xn;
     float totx = 0.f;
-    for (int b = 0; b < xn; ++b) totx += cubic_aa((b + xlo - cx + 0.5f) * invx);
+    for (int b = 0; b < xn; ++b) { const float w = cubic_aa((b + xlo - cx + 0.5f) * invx); if (b < AUG_WX_TAPS) wx[b][tid] = w; totx += w; }
     const float rtx = 1.f / totx;
-    for (int c = 0; c < C; ++c) {
-      const float mu = mean[c], is = inv_std[c];
-      float acc = 0.f;
-      for (int a = 0; a < yn; ++a) {
-        int yy = bi + ylo + a; yy = vf ? H - 1 - yy : yy;          // row of the flipped image -> row of the stored image
-        const unsigned char* rowp = img + ((long long)yy * Wmax) * C + c;
-        float hsum = 0.f;
-        for (int b = 0; b < xn; ++b) {
-          int xx = bj + xlo + b; xx = hf ? W - 1 - xx : xx;
-          const float v = ((float)rowp[(long long)xx * C] * (1.f / 255.f) - mu) * is;
-          hsum += cubic_aa((b + xlo - cx + 0.5f) * invx) * rtx * v;
-        }
-        acc += wy[a] * hsum;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+    // source column of tap b in the stored (un-flipped) image, stepping by +-C bytes
+    const int x0 = hf ? W - 1 - (bj + xlo) : bj + xlo;
+    const int xstep = hf ? -C : C;
+    for (int a = 0; a < yn; ++a) {
+      int yy = bi + ylo + a; yy = vf ? H - 1 - yy : yy;          // row of the flipped image -> row of the stored image
+      const unsigned char* px = img + ((long long)yy * Wmax + x0) * C;
+      const float wa = wy[a] * rtx;
+      for (int b = 0; b < xn; ++b, px += xstep) {
+        const float w = wa * (b < AUG_WX_TAPS ? wx[b][tid] : cubic_aa((b + xlo - cx + 0.5f) * invx));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (c < C) acc[c] = fmaf(w, (float)px[c], acc[c]);
       }
-      dst[((n * C + c) * S + oy) * (long long)S + ox] = acc;
     }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (c < C) dst[((n * C + c) * S + oy) * (long long)S + ox] = acc[c] * (inv_std[c] * (1.f / 255.f)) - mean[c] * inv_std[c];
   }
 }
 extern "C" int csmae_augment_u8(long long N, int C, int Hmax, int Wmax, int S, const unsigned char* src, const int* meta, const float* mean,
                                 const float* inv_std, float* dst, void* stream) {
-  CSMAE_REQUIRE(N > 0 && C > 0 && Hmax > 0 && Wmax > 0 && S > 0 && src && meta && mean && inv_std && dst, "csmae_augment_u8: bad arguments");
-  hipLaunchKernelGGL(augment_u8_kernel, dim3((unsigned)N, (unsigned)S), dim3(256), 0, (hipStream_t)stream, C, Hmax, Wmax, S, src, meta, mean, inv_std, dst);
+  CSMAE_REQUIRE(N > 0 && C > 0 && C <= AUG_MAX_C && Hmax > 0 && Wmax > 0 && S > 0 && src && meta && mean && inv_std && dst, "csmae_augment_u8: bad arguments (C <= 8)");
+  dim3 grid((unsigned)N, (unsigned)S);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 3) hipLaunchKernelGGL((augment_u8_kernel<3>), grid, dim3(256), 0, st, C, Hmax, Wmax, S, src, meta, mean, inv_std, dst);
+  else if (C == 4) hipLaunchKernelGGL((augment_u8_kernel<4>), grid, dim3(256), 0, st, C, Hmax, Wmax, S, src, meta, mean, inv_std, dst);
+  else hipLaunchKernelGGL((augment_u8_kernel<0>), grid, dim3(256), 0, st, C, Hmax, Wmax, S, src, meta, mean, inv_std, dst);
   return csmae_check_launch("csmae_augment_u8");
 }
