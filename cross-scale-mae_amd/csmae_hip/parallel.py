@@ -33,7 +33,7 @@ class GradSync:
         self._staging = torch.empty(flat_grad.numel(), dtype=comm_dtype, device=flat_grad.device) if comm_dtype not in (None, flat_grad.dtype) else None
         self._pending = False
         # gloo has no AVG; RCCL does
-        self._avg = self.cuda
+        self._avg = self.cuda and is_dist() and dist.get_backend(group) == "nccl"
 
     def reduce_range(self, lo: int, hi: int):
         """Enqueue mean-all-reduce of g[lo:hi].  On GPU it runs on the side stream after everything already enqueued on the

@@ -120,3 +120,59 @@ def test_data_parallel_world1_rccl_matches_plain():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _dp_two_rank_worker(rank, world, port, out_dir):
+    """Two processes on the ONE GPU of the test box, gloo as the transport (RCCL refuses two ranks on one device): exercises the
+    world_size > 1 control flow of DataParallel + Engine.backward on real kernels — rank-0 broadcast, gradient-ready ranges,
+    side-stream joins, BatchNorm buffer broadcast, no_sync."""
+    import torch.distributed as dist
+    import models_mae
+    from csmae_hip.optim import FusedAdamW, add_weight_decay
+    from csmae_hip.parallel import DataParallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        micro = dict(dim_model=128, encoder_num_layers=6, encoder_num_heads=2, decoder_embed_dim=64, decoder_num_layers=2, decoder_num_heads=2)
+        torch.manual_seed(100 + rank)  # different initial weights per rank: the wrapper must broadcast rank 0's
+        m = models_mae.MAE_ViT_MsLdCeCd(**micro, input_size=64, predictor_hidden_size=128).cuda().train()
+        w = DataParallel(m)
+        opt = FusedAdamW(add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+        x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(10 + rank)).cuda()
+        g = torch.Generator().manual_seed(20 + rank)
+        grads = None
+        for step in range(3):
+            m._test_draws = dict(noise=[torch.rand(4, 16, generator=g), torch.rand(4, 16, generator=g)], box=(7, 2, 45, 48))
+            opt.zero_grad(set_to_none=True)
+            if step == 1:  # accumulation micro-step: no exchange, gradients stay local
+                with w.no_sync():
+                    loss, _, _ = w(x)
+                    loss.backward()
+                m._test_draws = dict(noise=[torch.rand(4, 16, generator=g), torch.rand(4, 16, generator=g)], box=(7, 2, 45, 48))
+            loss, _, _ = w(x)
+            loss.backward()
+            if step == 0:
+                grads = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+            opt.step()
+        torch.cuda.synchronize()
+        torch.save(dict(params={n: p.detach().cpu() for n, p in m.named_parameters()}, grads=grads, loss=float(loss.detach()),
+                        bn=m.predictor[1].running_mean.detach().cpu()), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_on_one_gpu_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29600 + os.getpid() % 200
+    mp.spawn(_dp_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"])
+    # gradients after the exchange are the mean over ranks -> identical on both; so are the parameters after three AdamW steps
+    for n in r0["grads"]:
+        torch.testing.assert_close(r0["grads"][n], r1["grads"][n], rtol=0, atol=0)
+    for n in r0["params"]:
+        torch.testing.assert_close(r0["params"][n], r1["params"][n], rtol=0, atol=0)
+    # ... and they are not simply rank 0's local gradients: the two ranks saw different data
+    m = max(float((r0["grads"][n]).abs().max()) for n in r0["grads"])
+    assert m > 0
