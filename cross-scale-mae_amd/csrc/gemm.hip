@@ -19,6 +19,12 @@
 #include "common.h"
 #include <type_traits>
 #include <cstdlib>
+#include <utility>
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #define EPI_NONE 0    // C = acc + bias
 #define EPI_GELU 1    // x = acc + bias ; C = gelu(x) ; aux = gelu'(x)
@@ -529,10 +535,26 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
                       : ((((wm >> 4) ^ ((t >> 2) | ((g & 1) << 2))) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BM * 2));
   const int rb0 = !TB ? (wn + t) * 128 + ((g ^ (t & 7)) << 4)
                       : ((((wn >> 4) ^ ((t >> 2) | ((g & 1) << 2))) << 5) + (t & 3) * 8 + (8 * g + (t >> 2)) * (BN * 2));
-  auto read_a = [&](int slot, int h, int i, s8_t& fa) {
+  // K-contiguous-A kernels issue their fragment reads from inline assembly and count lgkmcnt by hand:
+  //  * "+v" re-reads an A fragment into the very registers the row's MFMAs just consumed — through plain C++ the compiler renames
+  //    the value and carries up to 32 extra fragment VGPRs through the loop;
+  //  * at the loop head the compiler cannot know how many reads the previous iteration left in flight and drains them all
+  //    (lgkmcnt(0) right after this step's four B reads were issued: ~150 clk per K step); the hand count lets them fly.
+  // Read order per step (steady state): B1 x BOPS | row i: A1_i | barrier | A0'_0 A0'_1 B0' x BOPS | row i >= 2: A0'_i.
+  constexpr bool USE_ASM = !TA;
+  constexpr int BOPS = TB ? 2 * FN : FN;                 // LDS instructions of one B fragment set
+  constexpr int W0_0 = (FM - 2) + BOPS;                  // before row 0 of a step: A0'_2.. and B1 may be in flight
+  constexpr int W0_I = (FM - 1) + BOPS;                  // before row i >= 2: (FM-1-i) A0' + B1 + i A1 reads are younger
+  constexpr int W1 = FM - 2;                             // before the two pre-barrier rows of the second half
+  static_assert(W0_I <= 15, "lgkmcnt is a 4-bit counter");
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+  auto read_a = [&](int slot, int h, auto ic, s8_t& fa) {
+    constexpr int i = decltype(ic)::value;
     const char* sa = smem + slot * UNIT;
-    if (!TA) fa = *reinterpret_cast<const s8_t*>(sa + (ra0 ^ (h << 6)) + i * 2048);
-    else {
+    if (!TA) {  // one address register per (slot, half); the fragment index is the instruction's immediate offset
+      const unsigned addr = lds0 + (unsigned)(slot * UNIT) + (unsigned)(ra0 ^ (h << 6));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(fa) : "v"(addr), "n"(i * 2048));
+    } else {
       s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + (ra0 ^ (i << 5)) + h * (32 * BM * 2)));
       s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sa + (ra0 ^ (i << 5)) + h * (32 * BM * 2) + 4 * BM * 2));
       fa = join_s4(lo, hi);
@@ -542,13 +564,31 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
     const char* sb = smem + slot * UNIT;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      if (!TB) fb[j] = *reinterpret_cast<const s8_t*>(sb + (rb0 ^ (h << 6)) + j * 2048);
+      if (USE_ASM && !TB) {
+        const unsigned addr = lds0 + (unsigned)(slot * UNIT) + (unsigned)(rb0 ^ (h << 6));
+        if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(addr));
+        else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fb[1]) : "v"(addr));
+        else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[2]) : "v"(addr));
+        else asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(fb[3]) : "v"(addr));
+      } else if (USE_ASM) {
+        const unsigned addr = lds0 + (unsigned)(slot * UNIT) + (unsigned)((rb0 ^ (j << 5)) + h * (32 * BN * 2));
+        s4_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi) : "v"(addr));
+        fb[j] = join_s4(lo, hi);
+      } else if (!TB) fb[j] = *reinterpret_cast<const s8_t*>(sb + (rb0 ^ (h << 6)) + j * 2048);
       else {
         s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + (rb0 ^ (j << 5)) + h * (32 * BN * 2)));
         s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, sb + (rb0 ^ (j << 5)) + h * (32 * BN * 2) + 4 * BN * 2));
         fb[j] = join_s4(lo, hi);
       }
     }
+  };
+  // hand-counted wait, tied to the registers the following MFMAs read so that the compiler cannot hoist them above it
+  auto wait_a = [&](auto n, s8_t& f0) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f0) : "n"(decltype(n)::value)); };
+  auto wait_ab = [&](auto n, s8_t& f0, s8_t& f1, s8_t (&fb)[FN]) {
+    static_assert(FN == 4, "four B fragments");
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f0), "+v"(f1), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) : "n"(decltype(n)::value));
   };
   // bias gradient (sum_k A(m,k), weight-gradient products only) on the VALU slots the MFMAs leave free: on the tn == 0 tiles wave
   // (wm, wq) sums fragments 2wq and 2wq+1, which its three wn-neighbours hold as well.  The branch is wave-uniform and contains
@@ -591,9 +631,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   __builtin_amdgcn_s_barrier();
   GTS(1);
   s8_t fa[FM], fb0[FN], fb1[FN];
+  if (USE_ASM) {  // (asm reads carry their destination as "+v": give the registers a defined value once)
 #pragma unroll
-  for (int i = 0; i < FM; ++i) read_a(0, 0, i, fa[i]);
+    for (int i = 0; i < FM; ++i) fa[i] = s8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  read_a(0, 0, std::integral_constant<int, 0>{}, fa[0]); read_a(0, 0, std::integral_constant<int, 1>{}, fa[1]);  // order of the in-loop prefetch: A_0 A_1 B A_2 ...
   read_b(1, 0, fb0);
+  static_for<FM - 2>([&](auto ic) { constexpr int i = decltype(ic)::value + 2; read_a(0, 0, std::integral_constant<int, i>{}, fa[i]); });
   auto nxt = [](int s, int k) { s += k; return s >= NUNIT ? s - NUNIT : s; };
   // MODE 0: fetch units 2j+5 (B of step j+2) and 2j+6 (A of step j+3), prefetch step j+1   1: fetch 2j+5 only   2: nothing left to
   // fetch   3: last step (nothing to prefetch either)
@@ -602,12 +646,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
     constexpr bool more = MODE < 3;
     const int sl1 = nxt(sl, 1), sl2 = nxt(sl, 2), sl3 = nxt(sl, 3);
     read_b(sl1, 1, fb1);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    static_for<FM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (USE_ASM) {
+        if (i == 0) wait_ab(std::integral_constant<int, W0_0>{}, fa[0], fa[1], fb0);
+        else if (i >= 2) wait_a(std::integral_constant<int, W0_I>{}, fa[i]);
+      }
       mma_row(i, fa[i], fb0);
-      read_a(sl, 1, i, fa[i]);
+      read_a(sl, 1, ic, fa[i]);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
+    if (USE_ASM) wait_ab(std::integral_constant<int, W1>{}, fa[0], fa[1], fb1);
     mma_row(0, fa[0], fb1);
     mma_row(1, fa[1], fb1);
     __builtin_amdgcn_sched_barrier(0);
@@ -616,7 +665,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (more) { read_a(sl2, 0, 0, fa[0]); read_a(sl2, 0, 1, fa[1]); read_b(sl3, 0, fb0); }
+    if (more) { read_a(sl2, 0, std::integral_constant<int, 0>{}, fa[0]); read_a(sl2, 0, std::integral_constant<int, 1>{}, fa[1]); read_b(sl3, 0, fb0); }
     // the PPU + PPA pieces of the two units: one per remaining row, the surplus right here
     constexpr int NPC = PPU + PPA, FIRST = NPC - (FM - 2);
     auto piece = [&](int pc) {
@@ -626,13 +675,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
 #pragma unroll
     for (int pc = 0; pc < FIRST; ++pc) piece(pc);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 2; i < FM; ++i) {
+    static_for<FM - 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value + 2;
       mma_row(i, fa[i], fb1);
-      if (more) read_a(sl2, 0, i, fa[i]);
+      if (more) read_a(sl2, 0, std::integral_constant<int, i>{}, fa[i]);
       piece(FIRST + i - 2);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
   };
   int j = 0, sl = 0;
   for (; j < nsteps - 3; ++j, sl = nxt(sl, 2)) step(kt_begin + j, sl, std::integral_constant<int, 0>{});
