@@ -30,14 +30,15 @@ Tensor = torch.Tensor
 def make_cfg(input_size=128, input_channels=3, patch_size=16, dim_model=1024, encoder_num_layers=24,
              encoder_num_heads=16, decoder_embed_dim=512, decoder_num_layers=8, decoder_num_heads=16,
              predictor_hidden_size=2048, loss="mse", norm_pix_loss=False, ms_range=(0.25, 0.75),
-             ms_decoder_loss_reduction="sum", variant="MsLdCeCd", **_):
+             ms_decoder_loss_reduction="sum", variant="MsLdCeCd", loss_cd=None, loss_e=None, **_):
     """Geometry of one model; defaults follow `models_mae/MAE_ViT_Baseline.py:17-49`."""
     p = int(patch_size)
     g = input_size // p
     return dict(S=input_size, C=input_channels, p=p, G=g, L=g * g, D=dim_model, He=encoder_num_heads,
                 Ne=encoder_num_layers, Dd=decoder_embed_dim, Hd=decoder_num_heads, Nd=decoder_num_layers,
                 Hp=predictor_hidden_size, loss=loss.lower(), norm_pix=bool(norm_pix_loss),
-                ms_range=tuple(ms_range), reduction=ms_decoder_loss_reduction.lower(), variant=variant)
+                ms_range=tuple(ms_range), reduction=ms_decoder_loss_reduction.lower(), variant=variant,
+                loss_cd=(loss_cd or loss).lower(), loss_e=(loss_e or loss).lower())  # MAE_ViT_MsLdCeCd.py:17-18, MsLdLe.py:14-15
 
 
 PRESETS = {  # `models_mae/__init__.py:23-67`
@@ -103,7 +104,7 @@ def _reduce(per_patch: Tensor, mask: Optional[Tensor]) -> Tensor:
     return (per_patch * mask).sum() / mask.sum() if mask is not None else per_patch.mean()
 
 
-def loss_fn(kind: str, target: Tensor, pred: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+def loss_fn(kind: str, target: Tensor, pred: Tensor, mask: Optional[Tensor] = None, p: Optional[int] = None, c: Optional[int] = None) -> Tensor:
     if kind == "mse":
         return _reduce(((pred - target) ** 2).mean(-1), mask)
     if kind == "l2":
@@ -115,7 +116,99 @@ def loss_fn(kind: str, target: Tensor, pred: Tensor, mask: Optional[Tensor] = No
     if kind == "bce":
         t01 = (target - target.min()) / (target.max() - target.min() + 1.0e-6)
         return _reduce(F.binary_cross_entropy_with_logits(pred, t01, reduction="none").mean(-1), mask)
-    raise ValueError(f"loss {kind!r} is outside the hot-path scope (SURVEY §2 row 2)")
+    if kind in SSIM_KINDS:  # MAE_ViT_Shared.py:165-267
+        if p is None or c is None:
+            raise ValueError("the ssim family works on images: patch size and channel count are required")
+        return ssim_family_loss(kind, target, pred, mask, p, c)
+    raise ValueError(f"unknown loss {kind!r}")
+
+
+# ------------------------------------------------ pytorch-msssim 0.2.1 (`env.yml:118`; call sites MAE_ViT_Shared.py:204,247)
+# PARITY UNPINNED for this block: the package is not in the reference tree and not installed here, so its
+# published algorithm is restated (Wang et al. 2004 / Wang et al. 2003 as implemented by pytorch-msssim 0.2.1:
+# separable 11-tap gaussian, sigma 1.5, "valid" windows, K = (0.01, 0.03), five scales with 2x2 average pooling
+# padded by `size % 2`).  tests/test_oracle_golden.py cross-checks it against an independent float64 scipy
+# formulation and known answers; the reference-owned wiring around it (scale_01, unpatchify, mask, 1 - ssim,
+# the 0.1 weight) is pinned against the reference itself with this restatement injected (tests/golden/ssim_loss.npz).
+SSIM_KINDS = ("ssim", "ms_ssim", "mse_ssim", "mse_ms_ssim")
+MS_SSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def gaussian_window(size: int = 11, sigma: float = 1.5) -> Tensor:
+    coords = torch.arange(size, dtype=torch.float32) - size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def gaussian_filter(x: Tensor, win: Tensor) -> Tensor:
+    """Depth-wise separable "valid" blur of [N,C,H,W]: along H first, then along W; an axis shorter than the
+    window is left unfiltered (the package warns and skips it)."""
+    ch = x.shape[1]
+    out = x
+    if x.shape[2] >= win.numel():
+        out = F.conv2d(out, win.view(1, 1, -1, 1).repeat(ch, 1, 1, 1), groups=ch)
+    if x.shape[3] >= win.numel():
+        out = F.conv2d(out, win.view(1, 1, 1, -1).repeat(ch, 1, 1, 1), groups=ch)
+    return out
+
+
+def ssim_maps(x: Tensor, y: Tensor, data_range: float, win: Tensor, k=(0.01, 0.03)):
+    """-> (ssim per (n, c), contrast-structure per (n, c)): spatial means of the two maps."""
+    c1, c2 = (k[0] * data_range) ** 2, (k[1] * data_range) ** 2
+    mu1, mu2 = gaussian_filter(x, win), gaussian_filter(y, win)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = gaussian_filter(x * x, win) - mu1_sq
+    s2 = gaussian_filter(y * y, win) - mu2_sq
+    s12 = gaussian_filter(x * y, win) - mu12
+    cs_map = (2 * s12 + c2) / (s1 + s2 + c2)
+    ssim_map = ((2 * mu12 + c1) / (mu1_sq + mu2_sq + c1)) * cs_map
+    return ssim_map.flatten(2).mean(-1), cs_map.flatten(2).mean(-1)
+
+
+def ssim(x: Tensor, y: Tensor, data_range: float = 255, size_average: bool = True, win_size: int = 11,
+         win_sigma: float = 1.5, nonnegative_ssim: bool = False) -> Tensor:
+    per_ch, _ = ssim_maps(x, y, data_range, gaussian_window(win_size, win_sigma).to(x.dtype))
+    if nonnegative_ssim:
+        per_ch = torch.relu(per_ch)
+    return per_ch.mean() if size_average else per_ch.mean(1)
+
+
+def ms_ssim(x: Tensor, y: Tensor, data_range: float = 255, size_average: bool = True, win_size: int = 11,
+            win_sigma: float = 1.5, weights=MS_SSIM_WEIGHTS) -> Tensor:
+    assert min(x.shape[-2:]) > (win_size - 1) * 2 ** 4, "Image size should be larger than 160 due to the 4 downsamplings in ms-ssim"
+    win = gaussian_window(win_size, win_sigma).to(x.dtype)
+    w = torch.tensor(weights, dtype=x.dtype)
+    terms = []
+    for lvl in range(len(weights)):
+        per_ch, cs = ssim_maps(x, y, data_range, win)
+        if lvl < len(weights) - 1:
+            terms.append(torch.relu(cs))
+            pad = [s % 2 for s in x.shape[2:]]
+            x = F.avg_pool2d(x, kernel_size=2, padding=pad)
+            y = F.avg_pool2d(y, kernel_size=2, padding=pad)
+    terms.append(torch.relu(per_ch))
+    val = torch.prod(torch.stack(terms, 0) ** w.view(-1, 1, 1), dim=0)
+    return val.mean() if size_average else val.mean(1)
+
+
+def scale_01(x: Tensor) -> Tensor:  # MAE_ViT_Shared.py:94-95 — over the WHOLE tensor
+    return (x - x.min()) / (x.max() - x.min() + 1.0e-6)
+
+
+def ssim_family_loss(kind: str, target: Tensor, pred: Tensor, mask: Optional[Tensor], p: int, c: int) -> Tensor:
+    """MAE_ViT_Shared.py:165-267.  `target`/`pred` are [N, L, p*p*c]; both are min-max scaled separately,
+    un-patchified, multiplied by the patch mask (hard-coded 3 channels in the reference, :194-196), and
+    compared with ssim(data_range=1, nonnegative_ssim=True) or ms_ssim(data_range=1).  The `mse_*` kinds add
+    0.1 x that to the masked mse."""
+    if kind.startswith("mse_"):
+        return loss_fn("mse", target, pred, mask) + 0.1 * ssim_family_loss(kind[4:], target, pred, mask, p, c)
+    t, q = unpatchify(scale_01(target), p, c), unpatchify(scale_01(pred), p, c)
+    if mask is not None:
+        m = unpatchify(mask.unsqueeze(-1).repeat(1, 1, p * p * 3), p, c)
+        t, q = t * m, q * m
+    if kind == "ssim":
+        return 1 - ssim(q, t, data_range=1, size_average=True, nonnegative_ssim=True)
+    return 1 - ms_ssim(q, t, data_range=1, size_average=True)
 
 
 def recon_target(imgs: Tensor, p: int, c: int, norm_pix: bool) -> Tensor:
@@ -172,7 +265,7 @@ def decoder(sd, cfg, latent: Tensor, ids_restore: Tensor):
 def baseline(sd, cfg, imgs, noise, mask_ratio=0.75):
     latent, mask, ids_restore = encoder(sd, cfg, imgs, noise, mask_ratio)
     pred, emb = decoder(sd, cfg, latent, ids_restore)
-    loss = loss_fn(cfg["loss"], recon_target(imgs, cfg["p"], cfg["C"], cfg["norm_pix"]), pred, mask)
+    loss = loss_fn(cfg["loss"], recon_target(imgs, cfg["p"], cfg["C"], cfg["norm_pix"]), pred, mask, cfg["p"], cfg["C"])
     return dict(loss=loss, pred=pred, mask=mask, ids_restore=ids_restore, enc=latent, dec=emb)
 
 
@@ -268,12 +361,12 @@ def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=
     total = loss_d
     out["loss_d"] = loss_d
     if variant in ("MsLdLe", "MsLdLeCd"):  # MAE_ViT_MsLdLe.py:44 — full [N,T,D] incl. cls, no mask
-        out["loss_e"] = loss_fn(cfg["loss"], vo["enc"], vc["enc"])
+        out["loss_e"] = loss_fn(cfg.get("loss_e", cfg["loss"]), vo["enc"], vc["enc"])
         total = total + out["loss_e"]
     if variant in ("MsLdCd", "MsLdLeCd", "MsLdCeCd"):  # MAE_ViT_MsLdCeCd.py:56-59 — target NOT detached
         cross_pred = predictor(sd, vc["dec"][:, 1:, :], bn=bn)
         out["cross_pred"] = cross_pred
-        out["loss_cd"] = loss_fn(cfg["loss"], vo["dec"][:, 1:, :], cross_pred)
+        out["loss_cd"] = loss_fn(cfg.get("loss_cd", cfg["loss"]), vo["dec"][:, 1:, :], cross_pred)
         total = total + out["loss_cd"]
     if variant == "MsLdCeCd":  # MAE_ViT_MsLdCeCd.py:61-69
         f1 = vo["enc"][:, 1:, :].mean(dim=1)

@@ -153,6 +153,40 @@ def g_patch_loss():
     np.savez_compressed(os.path.join(OUT, "patch_loss.npz"), **d)
 
 
+# ---------------------------------------------------------------- G4b ssim-family losses (§8 f-4)
+def g_ssim_loss():
+    """The reference's own `forward_loss_{ssim,ms_ssim,mse_ssim,mse_ms_ssim}` (scale_01, unpatchify, mask,
+    1 - ssim, the 0.1 weight) around ref_stubs' float64 formulation of pytorch-msssim 0.2.1; value and d/dpred."""
+    d = {}
+    g = torch.Generator().manual_seed(11)
+    kinds = ("ssim", "ms_ssim", "mse_ssim", "mse_ms_ssim")
+    with quiet():
+        mods = {k: models_mae.MAE_ViT_Baseline.__mro__[1](loss=k) for k in kinds}
+        mod_np = models_mae.MAE_ViT_Baseline.__mro__[1](loss="mse_ssim", norm_pix_loss=True)
+    # (tag, N, S, p): 64^2 for the single-scale kinds; 168^2 / p=8 for the five-scale ones (168 > 160; levels 168, 84, 42, 21, 11:
+    # level 3 is odd, so the padded pooling is covered).  Gradients are kept for the masked calls only (fixture size).
+    for tag, n, s, p, ks in [("s64", 2, 64, 16, ("ssim", "mse_ssim")), ("s168", 1, 168, 8, kinds)]:
+        L = (s // p) ** 2
+        imgs = torch.randn(n, 3, s, s, generator=g)
+        # a smooth image-like prediction plus noise, so that the structure terms are well away from the relu clamps
+        pred = (mods["ssim"].patchify(imgs, p, 3) * 0.7 + 0.5 * torch.randn(n, L, p * p * 3, generator=g)).requires_grad_(True)
+        mask = (torch.rand(n, L, generator=g) > 0.3).float()
+        d[f"{tag}_imgs"], d[f"{tag}_pred"], d[f"{tag}_mask"] = npy(imgs), npy(pred), npy(mask)
+        d[f"{tag}_p"] = np.array(p)
+        for k in ks:
+            loss = mods[k].forward_loss(imgs, pred, mask, p, 3)
+            d[f"{tag}_{k}_masked"] = npy(loss)
+            if not (tag == "s168" and k in ("ssim", "mse_ssim")):
+                (gr,) = torch.autograd.grad(loss, pred)
+                d[f"{tag}_{k}_masked_grad"] = npy(gr).astype(np.float32)
+            d[f"{tag}_{k}_nomask"] = npy(mods[k].forward_loss(imgs, pred, None, p, 3))
+        if tag == "s64":
+            loss = mod_np.forward_loss(imgs, pred, mask, p, 3)
+            (gr,) = torch.autograd.grad(loss, pred)
+            d[f"{tag}_mse_ssim_normpix"], d[f"{tag}_mse_ssim_normpix_grad"] = npy(loss), npy(gr)
+    np.savez_compressed(os.path.join(OUT, "ssim_loss.npz"), **d)
+
+
 # ------------------------------------------------------------------------------- G5 ntxent
 def g_ntxent():
     d = {}
@@ -558,6 +592,7 @@ def main():
     g_sincos()
     g_masking(tiny)
     g_patch_loss()
+    g_ssim_loss()
     g_ntxent()
     g_predictor()
     g_block()
@@ -569,4 +604,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # e.g. `python oracle/gen_golden.py g_ssim_loss`: regenerate one fixture
+        torch.set_num_threads(8)
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        main()

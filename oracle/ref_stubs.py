@@ -14,6 +14,10 @@ Only the two pieces of third-party *arithmetic* that sit on the hot path are res
   `models_mae/MAE_ViT_MsLd.py:29-35`): <=10 box proposals from the CPU torch RNG, centre-crop
   fallback, then bilinear anti-aliased resize.
 
+* pytorch-msssim 0.2.1 ``ssim`` / ``ms_ssim`` (call sites `models_mae/MAE_ViT_Shared.py:204,247`), in a
+  formulation that is deliberately *different* from the one in `csmae_oracle.py` (float64, dense 2-D window,
+  explicit 2x2 block means) so that the two check each other through the golden fixture.
+
 Everything else is an inert placeholder.  This file is never shipped to / needed on the GPU box.
 """
 from __future__ import annotations
@@ -141,6 +145,59 @@ def _mod(name, **attrs):
     return m
 
 
+# ----------------------------------------------------------------------- pytorch-msssim 0.2.1
+def _win2d(size, sigma):
+    c = torch.arange(size, dtype=torch.float64) - size // 2
+    g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+    g = g / g.sum()
+    return torch.outer(g, g)
+
+
+def _ssim_cs_64(x, y, data_range, size, sigma, k):
+    """Per-(n, c) spatial means of the SSIM map and of its contrast-structure factor, float64."""
+    ch = x.shape[1]
+    w = _win2d(size, sigma).view(1, 1, size, size).repeat(ch, 1, 1, 1)
+    blur = lambda t: F.conv2d(t, w, groups=ch)
+    c1, c2 = (k[0] * data_range) ** 2, (k[1] * data_range) ** 2
+    mx, my = blur(x), blur(y)
+    vx, vy, cxy = blur(x * x) - mx * mx, blur(y * y) - my * my, blur(x * y) - mx * my
+    cs = (2 * cxy + c2) / (vx + vy + c2)
+    lum = (2 * mx * my + c1) / (mx * mx + my * my + c1)
+    return (lum * cs).mean((2, 3)), cs.mean((2, 3))
+
+
+def _halve(t):
+    """avg_pool2d(kernel 2, stride 2, padding = size % 2, pad counted) written as explicit block means."""
+    ph, pw = t.shape[2] % 2, t.shape[3] % 2
+    t = F.pad(t, (pw, pw, ph, ph))
+    h2, w2 = t.shape[2] // 2, t.shape[3] // 2
+    t = t[:, :, :h2 * 2, :w2 * 2]
+    return t.reshape(t.shape[0], t.shape[1], h2, 2, w2, 2).mean((3, 5))
+
+
+def msssim_ssim(X, Y, data_range=255, size_average=True, win_size=11, win_sigma=1.5, win=None, K=(0.01, 0.03), nonnegative_ssim=False):
+    assert win is None and X.dim() == 4 and X.shape == Y.shape
+    s, _ = _ssim_cs_64(X.double(), Y.double(), data_range, win_size, win_sigma, K)
+    if nonnegative_ssim:
+        s = torch.relu(s)
+    return (s.mean() if size_average else s.mean(1)).to(X.dtype)
+
+
+def msssim_ms_ssim(X, Y, data_range=255, size_average=True, win_size=11, win_sigma=1.5, win=None, weights=None, K=(0.01, 0.03)):
+    assert win is None and X.dim() == 4 and X.shape == Y.shape
+    assert min(X.shape[-2:]) > (win_size - 1) * 2 ** 4
+    weights = [0.0448, 0.2856, 0.3001, 0.2363, 0.1333] if weights is None else weights
+    x, y = X.double(), Y.double()
+    val = None
+    for lvl, wgt in enumerate(weights):
+        s, cs = _ssim_cs_64(x, y, data_range, win_size, win_sigma, K)
+        term = torch.relu(s if lvl == len(weights) - 1 else cs) ** wgt
+        val = term if val is None else val * term
+        if lvl < len(weights) - 1:
+            x, y = _halve(x), _halve(y)
+    return (val.mean() if size_average else val.mean(1)).to(X.dtype)
+
+
 def install():
     """Put the stand-ins into sys.modules and the reference root on sys.path."""
     if REFERENCE_ROOT not in sys.path:
@@ -152,7 +209,7 @@ def install():
     timm.loss = _mod("timm.loss", SoftTargetCrossEntropy=dummy)
     xf = _mod("xformers")
     xf.factory = _mod("xformers.factory", xFormer=dummy, xFormerConfig=dummy)
-    _mod("pytorch_msssim", ssim=None, ms_ssim=None)
+    _mod("pytorch_msssim", ssim=msssim_ssim, ms_ssim=msssim_ms_ssim)
     _mod("wandb", log=lambda *a, **k: None)
     tv = _mod("torchvision")
     tv.transforms = _mod("torchvision.transforms", RandomResizedCrop=RandomResizedCrop)

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--atomic", action="store_true", help="weight gradients through the atomic split-K epilogue instead of slabs")
     ap.add_argument("--cfg", type=int, default=-1, help="force block tile: 0=128x128 1=256x128 2=256x256 3=256x256 ping-pong")
+    ap.add_argument("--lib", action="store_true", help="time torch.matmul (the vendor GEMM library, bf16 out, no epilogue) on the same shapes: a yardstick, not a product path")
     ap.add_argument("--dbg", type=int, default=0, help="ablation bits: 16 main loop only, 32 no DMA, 64 no MFMA, 128 no fragment reads")
     a = ap.parse_args()
     from csmae_hip.engine import Engine
@@ -65,7 +66,11 @@ def main():
         if epi == 4:
             sk = a.splitk or Engine._splitk(M, N, K, 128, 64)
         kw = dict(trans_a=ta, trans_b=tb, bias=bias, epilogue=epi, aux=aux, resid=resid, splitk=sk)
-        if epi == 4 and not a.atomic:
+        if a.lib:
+            Al, Bl = (A.t() if ta else A), (B if tb else B.t())
+            Cl = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            run = lambda: torch.matmul(Al, Bl, out=Cl)
+        elif epi == 4 and not a.atomic:
             ws = torch.empty(64 << 20, device=dev)
             run = lambda: ops.gemm_dw(A, B, C, ws)
         else:
