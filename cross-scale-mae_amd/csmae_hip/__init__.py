@@ -13,7 +13,9 @@ import torch  # noqa: F401  -- must come first: libcsmae_hip.so has to bind to t
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
-LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4}
+LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4, "none": 5}
+# the ssim family: kind -> (per-patch kind, pyramid levels, weight of the ssim term)  MAE_ViT_Shared.py:165-267
+SSIM_KINDS = {"ssim": ("none", 1, 1.0), "ms_ssim": ("none", 5, 1.0), "mse_ssim": ("mse", 1, 0.1), "mse_ms_ssim": ("mse", 5, 0.1)}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsmae_hip.so")
@@ -40,7 +42,11 @@ _SIGNATURES = {
     "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],
     "csmae_target_minmax": [I, L, I, I, I, I, P, P, P, P, P],
     "csmae_recon_loss_fwd": [I, I, L, I, I, I, I, P, P, P, L, P, P, P],
-    "csmae_recon_loss_bwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P, F, P, L, P],
+    "csmae_recon_loss_bwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P, F, P, P, L, P],
+    "csmae_ssim_workspace_floats": [L, I, I, I, I, P],
+    "csmae_ssim_fwd": [I, I, L, I, I, I, I, P, P, P, L, P, P, P, P],
+    "csmae_ssim_apply": [I, I, F, F, P, P, P],
+    "csmae_ssim_bwd": [I, L, I, I, I, I, P, L, P, P, F, P, P, P],
     "csmae_pair_loss_fwd": [I, L, I, P, L, L, L, P, L, L, L, P, P],
     "csmae_pair_loss_bwd": [I, I, L, I, P, L, L, L, P, L, L, L, P, F, P, P, P, P],
     "csmae_ntxent_fwd": [I, I, I, I, P, F, F, P, P, P, P, P, P],

@@ -24,7 +24,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, ops
+from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, SSIM_KINDS, ops
 
 _FROZEN = ("encoder_pos_embed", "decoder_pos_embed")
 
@@ -137,6 +137,11 @@ class Workspace:
         self.rowloss = E(B2 * L, **f32)
         self.minmax = E(4, **f32)
         self.mm_scratch = E(B2 * L * 2, **f32) if c["loss"] == "bce" else None
+        if c["loss"] in SSIM_KINDS:  # image planes per pyramid level + statistics, and the fp32 gradient share
+            _, levels, _ = SSIM_KINDS[c["loss"]]
+            self.ssim_ws = E(ops.ssim_workspace_floats(B2, c["C"], c["S"], c["p"], levels), **f32)
+            self.ssim_terms = E(2, **f32)
+            self.ssim_extra = E(B2 * L, c["P"], **f32)
         self.losses = torch.zeros(8, **f32)
         if eng.has_pred:
             Hp = c["Hp"]
@@ -423,10 +428,17 @@ class Engine:
                     ce_done.record(self.aux)
         kind, npx = c["loss"], c["norm_pix"]
         mm = None
+        ssim = SSIM_KINDS.get(kind)
+        if ssim is not None:  # MAE_ViT_Shared.py:165-267: (per-patch kind, pyramid levels, weight); the term joins `losses` after finalize
+            kind = ssim[0]
+            ops.ssim_fwd(ssim[1], npx, img0, img1, ws.pred, ws.mask, ws.ssim_ws, ws.ssim_terms, B2, N, c["C"], c["S"], c["p"], st=st)
         if kind == "bce":
             ops.target_minmax(img0, img1, ws.mm_scratch, ws.minmax, B2, N, c["C"], c["S"], c["p"], npx, st=st)
             mm = ws.minmax
-        ops.recon_loss_fwd(kind, npx, img0, img1, ws.pred, mm, ws.rowloss, B2, N, c["C"], c["S"], c["p"], st=st)
+        if kind == "none":
+            ws.rowloss.zero_()
+        else:
+            ops.recon_loss_fwd(kind, npx, img0, img1, ws.pred, mm, ws.rowloss, B2, N, c["C"], c["S"], c["p"], st=st)
         kw = {}
         if self.has_pred:
             kcd = c["loss_cd"]
@@ -449,6 +461,8 @@ class Engine:
             kw.update(ce_rowloss=ws.ce_rowloss, ce_rows=B2)
         rscale = 0.5 if (self.views == 2 and c["reduction"] == "mean") else 1.0
         ops.loss_finalize(N * L, self.views, ws.rowloss, ws.mask, rscale, ws.losses, st=st, **kw)
+        if ssim is not None:
+            ops.ssim_apply(kind == "none", self.views, ssim[2], rscale, ws.ssim_terms, ws.losses, st=st)
         self._saved = dict(img0=img0, img1=img1, N=N, keep=keep, mm=mm, rscale=rscale)
         return ws
 
@@ -529,8 +543,13 @@ class Engine:
         ws.gout.copy_(gout.reshape(1).to(torch.float32))
         kind, npx = c["loss"], c["norm_pix"]
         # reconstruction head
+        extra = None
+        ssim = SSIM_KINDS.get(kind)
+        if ssim is not None:
+            kind, extra = ssim[0], ws.ssim_extra
+            ops.ssim_bwd(ssim[1], ws.pred, ws.mask, ws.gout, sv["rscale"] * ssim[2], ws.ssim_ws, extra, B2, N, c["C"], c["S"], c["p"], st=st)
         ops.recon_loss_bwd(kind, npx, sv["img0"], sv["img1"], ws.pred, sv["mm"], ws.mask, ws.losses, ws.gout, sv["rscale"], ws.dpred_lp,
-                           B2, N, c["C"], c["S"], c["p"], st=st)
+                           B2, N, c["C"], c["S"], c["p"], extra=extra, st=st)
         self._dw(ws.dpred_lp, ws.emb_lp, "decoder_pred")
         ops.gemm(ws.dpred_lp, self._w_pred(), ws.demb, trans_b=True, st=st)
         if self.has_pred:

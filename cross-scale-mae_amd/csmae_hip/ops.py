@@ -3,6 +3,8 @@ torch's current stream; all tensors must live on the GPU, be contiguous in their
 by PyTorch.  No function here computes anything with torch ops."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, LOSS_KINDS, check, load
@@ -179,10 +181,31 @@ def recon_loss_fwd(kind, norm_pix, img0, img1, pred, minmax, rowloss, B2, N, C, 
                                       _p(rowloss), st if st is not None else stream()), "csmae_recon_loss_fwd")
 
 
-def recon_loss_bwd(kind, norm_pix, img0, img1, pred, minmax, mask, losses, gout, vscale, dpred, B2, N, C, S, p, st=None):
+def recon_loss_bwd(kind, norm_pix, img0, img1, pred, minmax, mask, losses, gout, vscale, dpred, B2, N, C, S, p, extra=None, st=None):
     check(load().csmae_recon_loss_bwd(LOSS_KINDS[kind], int(norm_pix), dt(dpred), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0),
-                                      _p(minmax), _p(mask), _p(losses), _p(gout), vscale, _p(dpred), dpred.stride(0),
+                                      _p(minmax), _p(mask), _p(losses), _p(gout), vscale, _p(extra), _p(dpred), dpred.stride(0),
                                       st if st is not None else stream()), "csmae_recon_loss_bwd")
+
+
+# ---- ssim family (MAE_ViT_Shared.py:165-267)
+def ssim_workspace_floats(B2, C, S, p, levels):
+    n = ctypes.c_longlong(0)
+    check(load().csmae_ssim_workspace_floats(B2, C, S, p, levels, ctypes.byref(n)), "csmae_ssim_workspace_floats")
+    return n.value
+
+
+def ssim_fwd(levels, norm_pix, img0, img1, pred, mask, ws, terms, B2, N, C, S, p, st=None):
+    check(load().csmae_ssim_fwd(levels, int(norm_pix), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0), _p(mask), _p(ws), _p(terms),
+                                st if st is not None else stream()), "csmae_ssim_fwd")
+
+
+def ssim_apply(pure, views, weight, recon_scale, terms, losses, st=None):
+    check(load().csmae_ssim_apply(int(pure), views, weight, recon_scale, _p(terms), _p(losses), st if st is not None else stream()), "csmae_ssim_apply")
+
+
+def ssim_bwd(levels, pred, mask, gout, scale, ws, extra, B2, N, C, S, p, st=None):
+    check(load().csmae_ssim_bwd(levels, B2, N, C, S, p, _p(pred), pred.stride(0), _p(mask), _p(gout), scale, _p(ws), _p(extra),
+                                st if st is not None else stream()), "csmae_ssim_bwd")
 
 
 def pair_loss_fwd(kind, rows, D, a, aview, t, tview, partial, st=None):

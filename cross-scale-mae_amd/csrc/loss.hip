@@ -10,6 +10,7 @@
 #define LOSS_MAE 2
 #define LOSS_L1 3
 #define LOSS_BCE 4
+#define LOSS_NONE 5  // no per-patch term (pure ssim / ms_ssim): the gradient is the ssim family's `extra` alone
 
 __device__ __forceinline__ float elem_loss(int kind, float pred, float t) {
   if (kind == LOSS_MSE || kind == LOSS_L2) { float d = pred - t; return d * d; }
@@ -20,6 +21,7 @@ __device__ __forceinline__ float elem_loss(int kind, float pred, float t) {
 __device__ __forceinline__ float elem_grad(int kind, float pred, float t) {  // d elem_loss / d pred
   if (kind == LOSS_MSE || kind == LOSS_L2) return 2.f * (pred - t);
   if (kind == LOSS_MAE || kind == LOSS_L1) { float d = pred - t; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+  if (kind == LOSS_NONE) return 0.f;
   return 1.f / (1.f + expf(-pred)) - t;
 }
 __device__ __forceinline__ bool mean_over_last(int kind) { return kind == LOSS_MSE || kind == LOSS_MAE || kind == LOSS_BCE; }
@@ -95,20 +97,22 @@ __global__ __launch_bounds__(256) void recon_fwd_kernel(PatchGeom g, int kind, i
   s = wave_sum(s);
   if (lane == 0) rowloss[pt] = mean_over_last(kind) ? s / g.P : s;
 }
-// dpred[n2, 1+l, e] = gout * vscale * mask / masksum(view) * f'(pred, t) / (P or 1) ; cls rows and pad columns are zeroed
+// dpred[n2, 1+l, e] = gout * vscale * mask / masksum(view) * f'(pred, t) / (P or 1) (+ extra[n2, l, e], the ssim family's share,
+// already scaled, which also reaches visible patches through scale_01's min / max) ; cls rows and pad columns are zeroed
 template <typename T>
 __global__ __launch_bounds__(256) void recon_bwd_kernel(PatchGeom g, int kind, int norm_pix, long long rows, const float* __restrict__ img0,
                                                         const float* __restrict__ img1, const float* __restrict__ pred, long long ldp,
                                                         const float* __restrict__ minmax, const float* __restrict__ mask,
                                                         const float* __restrict__ losses, const float* __restrict__ gout, float vscale,
-                                                        T* __restrict__ dpred, long long ldd) {
+                                                        const float* __restrict__ extra, T* __restrict__ dpred, long long ldd) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // row of [B2*(L+1)]
   if (row >= rows) return;
   const long long n2 = row / (g.L + 1); const int j = (int)(row - n2 * (g.L + 1));
   T* dp = dpred + row * ldd;
   float m = j > 0 ? mask[n2 * g.L + j - 1] : 0.f;
-  if (m == 0.f) { for (int e = lane; e < ldd; e += 64) st_from_f32<T>(dp + e, 0.f); return; }
+  const float* ex = (extra && j > 0) ? extra + (n2 * g.L + j - 1) * g.P : nullptr;
+  if (m == 0.f || kind == LOSS_NONE) { for (int e = lane; e < ldd; e += 64) st_from_f32<T>(dp + e, (ex && e < g.P) ? ex[e] : 0.f); return; }
   const int l = j - 1, v = (int)(n2 / g.N);
   const float* img = patch_img(g, img0, img1, n2);
   float mu = 0.f, rs = 1.f;
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(PatchGeom g, int kind, i
       float t = (patch_elem(g, img, l, e) - mu) * rs;
       if (kind == LOSS_BCE) t = (t - lo) * sc;
       o = coef * elem_grad(kind, pr[e], t);
+      if (ex) o += ex[e];
     }
     st_from_f32<T>(dp + e, o);
   }
@@ -149,13 +154,14 @@ extern "C" int csmae_recon_loss_fwd(int kind, int norm_pix, long long B2, int N,
 }
 extern "C" int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, long long B2, int N, int C, int S, int p, const float* img0,
                                     const float* img1, const float* pred, long long ldp, const float* minmax, const float* mask,
-                                    const float* losses, const float* gout, float vscale, void* dpred, long long ldd, void* stream) {
-  CSMAE_REQUIRE(kind >= LOSS_MSE && kind <= LOSS_BCE, "csmae_recon_loss_bwd: bad loss kind %d", kind);
+                                    const float* losses, const float* gout, float vscale, const float* extra, void* dpred, long long ldd,
+                                    void* stream) {
+  CSMAE_REQUIRE(kind >= LOSS_MSE && kind <= LOSS_NONE && (kind != LOSS_NONE || extra), "csmae_recon_loss_bwd: bad loss kind %d", kind);
   PatchGeom g = make_geom(N, C, S, p);
   long long rows = B2 * (g.L + 1);
   hipStream_t st = (hipStream_t)stream;
-  if (out_dtype == CSMAE_BF16) hipLaunchKernelGGL((recon_bwd_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, st, g, kind, norm_pix, rows, img0, img1, pred, ldp, minmax, mask, losses, gout, vscale, (bf16_t*)dpred, ldd);
-  else if (out_dtype == CSMAE_F32) hipLaunchKernelGGL((recon_bwd_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, g, kind, norm_pix, rows, img0, img1, pred, ldp, minmax, mask, losses, gout, vscale, (float*)dpred, ldd);
+  if (out_dtype == CSMAE_BF16) hipLaunchKernelGGL((recon_bwd_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, st, g, kind, norm_pix, rows, img0, img1, pred, ldp, minmax, mask, losses, gout, vscale, extra, (bf16_t*)dpred, ldd);
+  else if (out_dtype == CSMAE_F32) hipLaunchKernelGGL((recon_bwd_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, g, kind, norm_pix, rows, img0, img1, pred, ldp, minmax, mask, losses, gout, vscale, extra, (float*)dpred, ldd);
   else { csmae_set_error("csmae_recon_loss_bwd: bad dtype %d", out_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_recon_loss_bwd");
 }
@@ -326,6 +332,428 @@ extern "C" int csmae_latent_grad_finish(int lp_dtype, long long B2, int Te, int 
   if (lp_dtype == CSMAE_BF16) hipLaunchKernelGGL((latent_grad_finish_kernel<bf16_t>), grid, block, 0, st, rows, Te, D, dlat, dpool, inv_keep, (bf16_t*)dlat_lp);
   else hipLaunchKernelGGL((latent_grad_finish_kernel<float>), grid, block, 0, st, rows, Te, D, dlat, dpool, inv_keep, (float*)dlat_lp);
   return csmae_check_launch("csmae_latent_grad_finish");
+}
+
+// ------------------------------------------------------------------------------------------ ssim family
+// MAE_ViT_Shared.py:165-267 around pytorch-msssim 0.2.1 (`env.yml:118`): both operands are min-max scaled over the whole per-view
+// tensor (scale_01 :94-95), un-patchified, multiplied by the patch mask, then compared with ssim(data_range 1, nonnegative) or the
+// five-scale ms_ssim.  HBM-bound stencils: planes [B2*C][H][W] fp32 per level, an 11-tap separable gaussian ("valid" windows, the
+// H axis first as the package does), 32x32 tiles staged through LDS.  All reductions are two-stage and deterministic.
+//   workspace (floats): see SsimLayout.  X = prediction planes, Y = target planes, D = gradient w.r.t. X.
+#define SSIM_WIN 11
+#define SSIM_R (SSIM_WIN - 1)
+#define SSIM_TILE 32
+#define SSIM_MAX_LEVELS 5
+struct SsimWin { float w[SSIM_WIN]; };
+struct SsimLayout {
+  int levels, H[SSIM_MAX_LEVELS], Ho[SSIM_MAX_LEVELS], tiles[SSIM_MAX_LEVELS], pad[SSIM_MAX_LEVELS];
+  long long planes, X[SSIM_MAX_LEVELS], Y[SSIM_MAX_LEVELS], D[SSIM_MAX_LEVELS], part[SSIM_MAX_LEVELS], coef, val, mm, stat, total;
+  // stat: [views][8] = pred lo, hi, target lo, hi, tie-term A, tie-term B, (int) count lo, (int) count hi
+};
+static SsimLayout ssim_layout(long long B2, int C, int S, int p, int levels) {
+  SsimLayout L;
+  L.levels = levels; L.planes = B2 * C;
+  long long off = 0;
+  auto take = [&](long long n) { long long o = off; off += (n + 3) & ~3ll; return o; };
+  int h = S;
+  for (int l = 0; l < SSIM_MAX_LEVELS; ++l) {
+    L.H[l] = h; L.Ho[l] = h - SSIM_R; L.pad[l] = h & 1;
+    const int t = cdiv(h - SSIM_R > 0 ? h - SSIM_R : 1, SSIM_TILE);
+    L.tiles[l] = t * t;
+    if (l < levels) {
+      L.X[l] = take(L.planes * h * h); L.Y[l] = take(L.planes * h * h); L.D[l] = take(L.planes * h * h);
+      L.part[l] = take(L.planes * L.tiles[l] * 2);
+    } else L.X[l] = L.Y[l] = L.D[l] = L.part[l] = 0;
+    h = (h + 2 * (h & 1) - 2) / 2 + 1;  // avg_pool2d(kernel 2, stride 2, padding = h % 2)
+  }
+  L.coef = take(L.planes * SSIM_MAX_LEVELS * 2);
+  L.val = take(L.planes);
+  const long long patches = B2 * (long long)(S / p) * (S / p);
+  L.mm = take(patches * 2);
+  L.stat = take(2 * 8);
+  L.total = off;
+  return L;
+}
+static SsimWin ssim_window() {  // pytorch-msssim `_fspecial_gauss_1d(11, 1.5)` in fp32
+  SsimWin w; float s = 0.f;
+  for (int i = 0; i < SSIM_WIN; ++i) { float c = (float)(i - SSIM_WIN / 2); w.w[i] = expf(-(c * c) / (2.f * 1.5f * 1.5f)); s += w.w[i]; }
+  for (int i = 0; i < SSIM_WIN; ++i) w.w[i] /= s;
+  return w;
+}
+
+// per-patch min / max of the prediction rows (cls row excluded, pad columns excluded)
+__global__ __launch_bounds__(256) void pred_minmax_kernel(PatchGeom g, long long patches, const float* __restrict__ pred, long long ldp, float* __restrict__ mm) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= patches) return;
+  const long long n2 = pt / g.L; const int l = (int)(pt - n2 * g.L);
+  const float* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int e = lane; e < g.P; e += 64) { float v = pr[e]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  lo = -wave_max(-lo); hi = wave_max(hi);
+  if (lane == 0) { mm[pt * 2] = lo; mm[pt * 2 + 1] = hi; }
+}
+__global__ __launch_bounds__(256) void ssim_stat_store_kernel(int views, int which, const float* __restrict__ mmout, float* __restrict__ stat) {
+  if (threadIdx.x < views * 2) { int v = threadIdx.x >> 1, k = threadIdx.x & 1; stat[v * 8 + which * 2 + k] = mmout[v * 2 + k]; }
+  if (which == 0 && threadIdx.x < views * 2) reinterpret_cast<int*>(stat)[(threadIdx.x >> 1) * 8 + 6 + (threadIdx.x & 1)] = 0;
+}
+// level-0 planes: X = mask * scale_01(pred), Y = mask * scale_01(target); counts the elements that attain the prediction's min / max
+// (the backward of x.min() / x.max() spreads its gradient evenly over ties)
+__global__ __launch_bounds__(256) void ssim_prepare_kernel(PatchGeom g, int norm_pix, long long patches, const float* __restrict__ img0,
+                                                           const float* __restrict__ img1, const float* __restrict__ pred, long long ldp,
+                                                           const float* __restrict__ mask, float* __restrict__ stat, float* __restrict__ X,
+                                                           float* __restrict__ Y) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= patches) return;
+  const long long n2 = pt / g.L; const int l = (int)(pt - n2 * g.L), v = (int)(n2 / g.N);
+  const float* img = patch_img(g, img0, img1, n2);
+  float mu = 0.f, rs = 1.f;
+  if (norm_pix) patch_stats(g, img, l, lane, mu, rs);
+  const float plo = stat[v * 8], phi = stat[v * 8 + 1], tlo = stat[v * 8 + 2], thi = stat[v * 8 + 3];
+  const float psc = 1.f / (phi - plo + 1.0e-6f), tsc = 1.f / (thi - tlo + 1.0e-6f);
+  const float m = mask ? mask[pt] : 1.f;
+  const float* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
+  const int gh = l / g.G, gw = l - gh * g.G;
+  int nlo = 0, nhi = 0;
+  for (int e = lane; e < g.P; e += 64) {
+    const int c = e % g.C, r = e / g.C, ph = r / g.p, pw = r - ph * g.p;
+    const long long o = ((n2 * g.C + c) * g.S + gh * g.p + ph) * g.S + gw * g.p + pw;
+    const float pv = pr[e];
+    nlo += pv == plo; nhi += pv == phi;
+    X[o] = (pv - plo) * psc * m;
+    Y[o] = ((patch_elem(g, img, l, e) - mu) * rs - tlo) * tsc * m;
+  }
+  if (nlo) atomicAdd(reinterpret_cast<int*>(stat) + v * 8 + 6, nlo);
+  if (nhi) atomicAdd(reinterpret_cast<int*>(stat) + v * 8 + 7, nhi);
+}
+// 2x2 average pooling with `pad` rows / columns of zeros in front (count_include_pad): both operands of one level
+__global__ __launch_bounds__(256) void ssim_pool_kernel(long long planes, int H, int pad, int Hn, const float* __restrict__ X, const float* __restrict__ Y,
+                                                        float* __restrict__ Xn, float* __restrict__ Yn) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= planes * Hn * Hn) return;
+  const long long pl = i / ((long long)Hn * Hn); const int r = (int)(i - pl * Hn * Hn), y = r / Hn, x = r - y * Hn;
+  const float* px = X + pl * H * H; const float* py = Y + pl * H * H;
+  float sx = 0.f, sy = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int yy = 2 * y - pad + dy, xx = 2 * x - pad + dx;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < H) { sx += px[yy * H + xx]; sy += py[yy * H + xx]; }
+    }
+  Xn[i] = 0.25f * sx; Yn[i] = 0.25f * sy;
+}
+
+#define SSIM_C1 1.0e-4f   // (0.01 * data_range)^2, data_range = 1
+#define SSIM_C2 9.0e-4f   // (0.03 * data_range)^2
+// One 32x32 tile of the SSIM / contrast-structure maps of one plane -> part[plane][tile] = (sum ssim_map, sum cs_map)
+__global__ __launch_bounds__(256) void ssim_level_fwd_kernel(SsimWin win, int H, int Ho, int tiles_x, const float* __restrict__ X, const float* __restrict__ Y,
+                                                             float* __restrict__ part) {
+  constexpr int T = SSIM_TILE, E = T + SSIM_R, ES = E + 1;
+  __shared__ float sx[E * ES], sy[E * ES], V[5][T * ES], red[32];
+  const long long pl = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, y0 = ty * T, x0 = tx * T;
+  const float* px = X + pl * H * H; const float* py = Y + pl * H * H;
+  for (int i = threadIdx.x; i < E * E; i += 256) {
+    const int r = i / E, c = i - r * E, gy = y0 + r, gx = x0 + c;
+    const bool ok = gy < H && gx < H;
+    sx[r * ES + c] = ok ? px[gy * H + gx] : 0.f;
+    sy[r * ES + c] = ok ? py[gy * H + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * E; i += 256) {  // along H
+    const int r = i / E, c = i - r * E;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SSIM_WIN; ++k) {
+      const float x = sx[(r + k) * ES + c], y = sy[(r + k) * ES + c], w = win.w[k];
+      a0 += w * x; a1 += w * y; a2 += w * (x * x); a3 += w * (y * y); a4 += w * (x * y);
+    }
+    V[0][r * ES + c] = a0; V[1][r * ES + c] = a1; V[2][r * ES + c] = a2; V[3][r * ES + c] = a3; V[4][r * ES + c] = a4;
+  }
+  __syncthreads();
+  float ss = 0.f, sc = 0.f;
+  for (int i = threadIdx.x; i < T * T; i += 256) {  // along W
+    const int r = i / T, c = i - r * T;
+    if (y0 + r >= Ho || x0 + c >= Ho) continue;
+    float f[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * V[q][r * ES + c + k];
+      f[q] = a;
+    }
+    const float mu1 = f[0], mu2 = f[1], m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
+    const float s1 = f[2] - m11, s2 = f[3] - m22, s12 = f[4] - m12;
+    const float cs = (2.f * s12 + SSIM_C2) / (s1 + s2 + SSIM_C2);
+    ss += ((2.f * m12 + SSIM_C1) / (m11 + m22 + SSIM_C1)) * cs;
+    sc += cs;
+  }
+  ss = block_sum(ss, red); sc = block_sum(sc, red);
+  if (threadIdx.x == 0) { part[(pl * gridDim.x + blockIdx.x) * 2] = ss; part[(pl * gridDim.x + blockIdx.x) * 2 + 1] = sc; }
+}
+// Per-plane means -> per-plane score -> per-view loss term, and the coefficients the backward needs:
+//   d(term_v) / d(mean ssim_map of level l, plane) = coef[plane][l][0],  d / d(mean cs_map) = coef[plane][l][1]   (already / Ho^2)
+// ssim: relu(mean) per plane (nonnegative_ssim), averaged.  ms_ssim: prod_l relu(.)^w_l with cs for l < 4 and ssim for l = 4; a
+// clamped factor zeroes the product and (threshold backward selects 0) every gradient of that plane.
+struct SsimStatArgs { int levels, tiles[SSIM_MAX_LEVELS], Ho[SSIM_MAX_LEVELS]; const float* part[SSIM_MAX_LEVELS]; };
+__global__ __launch_bounds__(1024) void ssim_stats_kernel(SsimStatArgs a, long long planes, int views, float* __restrict__ coef, float* __restrict__ val,
+                                                          float* __restrict__ terms) {
+  __shared__ float red[32];
+  const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
+  const long long per_view = planes / views;
+  for (long long pl = threadIdx.x; pl < planes; pl += blockDim.x) {
+    float ms[SSIM_MAX_LEVELS], mc[SSIM_MAX_LEVELS];
+    for (int l = 0; l < a.levels; ++l) {
+      float s = 0.f, c = 0.f;
+      for (int t = 0; t < a.tiles[l]; ++t) { s += a.part[l][(pl * a.tiles[l] + t) * 2]; c += a.part[l][(pl * a.tiles[l] + t) * 2 + 1]; }
+      const float inv = 1.f / ((float)a.Ho[l] * a.Ho[l]);
+      ms[l] = s * inv; mc[l] = c * inv;
+    }
+    float* cf = coef + pl * SSIM_MAX_LEVELS * 2;
+    for (int l = 0; l < SSIM_MAX_LEVELS * 2; ++l) cf[l] = 0.f;
+    const float base = -1.f / (float)per_view;
+    float v;
+    if (a.levels == 1) {
+      v = fmaxf(ms[0], 0.f);
+      cf[0] = ms[0] > 0.f ? base / ((float)a.Ho[0] * a.Ho[0]) : 0.f;
+    } else {
+      float t[SSIM_MAX_LEVELS]; bool pos = true;
+      v = 1.f;
+      for (int l = 0; l < a.levels; ++l) { t[l] = fmaxf(l == a.levels - 1 ? ms[l] : mc[l], 0.f); pos &= t[l] > 0.f; v *= powf(t[l], wts[l]); }
+      if (!pos) v = 0.f;
+      for (int l = 0; l < a.levels; ++l) {
+        const float d = pos ? base * wts[l] * v / t[l] / ((float)a.Ho[l] * a.Ho[l]) : 0.f;
+        cf[l * 2 + (l == a.levels - 1 ? 0 : 1)] = d;
+      }
+    }
+    val[pl] = v;
+  }
+  __syncthreads();
+  for (int vw = 0; vw < views; ++vw) {
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < per_view; i += blockDim.x) s += val[vw * per_view + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) terms[vw] = 1.f - s / (float)per_view;
+  }
+}
+// Gradient of one level w.r.t. its X plane, for one 32x32 tile of pixels:
+//   dX(p) = sum_q w(p - q) [G0(q) + 2 X(p) G1(q) + Y(p) G2(q)]  (+ 1/4 of the next level's gradient at the pooled position)
+// with, at every window position q (F = cs * (a * lum + b) is what the plane's score depends on):
+//   c = a lum + b,  G1 = dF/dE[xx] = -c cs / B2,  G2 = dF/dE[xy] = 2 c / B2,  G0 = dF/dmu1 = a cs (2 mu2 - 2 lum mu1) / B1 - 2 mu1 G1 - mu2 G2
+__global__ __launch_bounds__(256) void ssim_level_bwd_kernel(SsimWin win, int H, int Ho, int tiles_x, int lvl, const float* __restrict__ X,
+                                                             const float* __restrict__ Y, const float* __restrict__ coef,
+                                                             const float* __restrict__ Dn, int Hn, int pad, float* __restrict__ D) {
+  constexpr int T = SSIM_TILE, E1 = T + SSIM_R, E2 = T + 2 * SSIM_R, S1 = E1 + 1, S2 = E2 + 1;
+  __shared__ float sxy[2 * E2 * S2];       // X | Y over the 52x52 halo region, later G[3][42][43]
+  __shared__ float V[5 * E1 * S2];         // H-filtered quantities [5][42][53], later T[3][32][43]
+  static_assert(3 * E1 * S1 <= 2 * E2 * S2 && 3 * T * S1 <= 5 * E1 * S2, "aliases fit");
+  float* sx = sxy; float* sy = sxy + E2 * S2;
+  const long long pl = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, y0 = ty * T, x0 = tx * T;
+  const float* px = X + pl * H * H; const float* py = Y + pl * H * H;
+  const float ca = coef[pl * SSIM_MAX_LEVELS * 2 + lvl * 2], cb = coef[pl * SSIM_MAX_LEVELS * 2 + lvl * 2 + 1];
+  for (int i = threadIdx.x; i < E2 * E2; i += 256) {
+    const int r = i / E2, c = i - r * E2, gy = y0 - SSIM_R + r, gx = x0 - SSIM_R + c;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < H;
+    sx[r * S2 + c] = ok ? px[gy * H + gx] : 0.f;
+    sy[r * S2 + c] = ok ? py[gy * H + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < E1 * E2; i += 256) {  // along H: window rows q = y0 - 10 + r
+    const int r = i / E2, c = i - r * E2;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SSIM_WIN; ++k) {
+      const float x = sx[(r + k) * S2 + c], y = sy[(r + k) * S2 + c], w = win.w[k];
+      a0 += w * x; a1 += w * y; a2 += w * (x * x); a3 += w * (y * y); a4 += w * (x * y);
+    }
+    V[(0 * E1 + r) * S2 + c] = a0; V[(1 * E1 + r) * S2 + c] = a1; V[(2 * E1 + r) * S2 + c] = a2; V[(3 * E1 + r) * S2 + c] = a3; V[(4 * E1 + r) * S2 + c] = a4;
+  }
+  __syncthreads();
+  float* G = sxy;
+  for (int i = threadIdx.x; i < E1 * E1; i += 256) {  // along W, then the three coefficient maps
+    const int r = i / E1, c = i - r * E1, qy = y0 - SSIM_R + r, qx = x0 - SSIM_R + c;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (qy >= 0 && qy < Ho && qx >= 0 && qx < Ho) {
+      float f[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * V[(q * E1 + r) * S2 + c + k];
+        f[q] = a;
+      }
+      const float mu1 = f[0], mu2 = f[1], m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
+      const float s1 = f[2] - m11, s2 = f[3] - m22, s12 = f[4] - m12;
+      const float B1 = m11 + m22 + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
+      const float lum = (2.f * m12 + SSIM_C1) / B1, cs = (2.f * s12 + SSIM_C2) / B2;
+      const float cc = ca * lum + cb;
+      g1 = -cc * cs / B2;
+      g2 = 2.f * cc / B2;
+      g0 = ca * cs * (2.f * mu2 - 2.f * lum * mu1) / B1 - 2.f * mu1 * g1 - mu2 * g2;
+    }
+    G[(0 * E1 + r) * S1 + c] = g0; G[(1 * E1 + r) * S1 + c] = g1; G[(2 * E1 + r) * S1 + c] = g2;
+  }
+  __syncthreads();
+  float* Tt = V;
+  for (int i = threadIdx.x; i < 3 * T * E1; i += 256) {  // transposed filter along H: rows p = y0 + r take windows q = p - k
+    const int m = i / (T * E1), j = i - m * T * E1, r = j / E1, c = j - r * E1;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * G[(m * E1 + r + SSIM_R - k) * S1 + c];
+    Tt[(m * T + r) * S1 + c] = a;
+  }
+  __syncthreads();
+  float* pd = D + pl * H * H;
+  const float* pn = Dn ? Dn + pl * Hn * Hn : nullptr;
+  for (int i = threadIdx.x; i < T * T; i += 256) {
+    const int r = i / T, c = i - r * T, gy = y0 + r, gx = x0 + c;
+    if (gy >= H || gx >= H) continue;
+    float o[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * Tt[(m * T + r) * S1 + c + SSIM_R - k];
+      o[m] = a;
+    }
+    float d = o[0] + 2.f * px[gy * H + gx] * o[1] + py[gy * H + gx] * o[2];
+    if (pn) { const int yy = (gy + pad) >> 1, xx = (gx + pad) >> 1; if (yy < Hn && xx < Hn) d += 0.25f * pn[yy * Hn + xx]; }
+    pd[gy * H + gx] = d;
+  }
+}
+// extra[pt][e] = gout * scale * dX0 * mask / range  (d loss / d pred through the scaled value), per-patch partial sums of the two
+// terms that flow into the tensor's min and max:  A = sum dxs (xs - 1) / range,  B = -sum dxs xs / range
+__global__ __launch_bounds__(256) void ssim_pred_bwd_kernel(PatchGeom g, long long patches, const float* __restrict__ pred, long long ldp,
+                                                            const float* __restrict__ mask, const float* __restrict__ stat, const float* __restrict__ D0,
+                                                            const float* __restrict__ gout, float scale, float* __restrict__ extra, float* __restrict__ ab) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= patches) return;
+  const long long n2 = pt / g.L; const int l = (int)(pt - n2 * g.L), v = (int)(n2 / g.N);
+  const float m = mask ? mask[pt] : 1.f;
+  float* ex = extra + pt * g.P;
+  float A = 0.f, B = 0.f;
+  if (m == 0.f) { for (int e = lane; e < g.P; e += 64) ex[e] = 0.f; }
+  else {
+    const float plo = stat[v * 8], psc = 1.f / (stat[v * 8 + 1] - plo + 1.0e-6f), gs = gout[0] * scale * m;
+    const float* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
+    const int gh = l / g.G, gw = l - gh * g.G;
+    for (int e = lane; e < g.P; e += 64) {
+      const int c = e % g.C, r = e / g.C, ph = r / g.p, pw = r - ph * g.p;
+      const float dxs = D0[((n2 * g.C + c) * g.S + gh * g.p + ph) * g.S + gw * g.p + pw] * gs;
+      const float xs = (pr[e] - plo) * psc;
+      ex[e] = dxs * psc;
+      A += dxs * (xs - 1.f) * psc; B -= dxs * xs * psc;
+    }
+  }
+  A = wave_sum(A); B = wave_sum(B);
+  if (lane == 0) { ab[pt * 2] = A; ab[pt * 2 + 1] = B; }
+}
+__global__ __launch_bounds__(1024) void ssim_tie_reduce_kernel(long long per_view, int views, const float* __restrict__ ab, float* __restrict__ stat) {
+  __shared__ float red[32];
+  for (int v = 0; v < views; ++v) {
+    float A = 0.f, B = 0.f;
+    for (long long i = threadIdx.x; i < per_view; i += blockDim.x) { A += ab[(v * per_view + i) * 2]; B += ab[(v * per_view + i) * 2 + 1]; }
+    A = block_sum(A, red); B = block_sum(B, red);
+    if (threadIdx.x == 0) {
+      const int* cnt = reinterpret_cast<const int*>(stat) + v * 8 + 6;
+      stat[v * 8 + 4] = A / (float)max(cnt[0], 1); stat[v * 8 + 5] = B / (float)max(cnt[1], 1);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ssim_tie_apply_kernel(PatchGeom g, long long patches, const float* __restrict__ pred, long long ldp,
+                                                             const float* __restrict__ stat, float* __restrict__ extra) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= patches) return;
+  const long long n2 = pt / g.L; const int l = (int)(pt - n2 * g.L), v = (int)(n2 / g.N);
+  const float plo = stat[v * 8], phi = stat[v * 8 + 1], A = stat[v * 8 + 4], B = stat[v * 8 + 5];
+  const float* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
+  for (int e = lane; e < g.P; e += 64) {
+    const float pv = pr[e];
+    if (pv == plo || pv == phi) extra[pt * g.P + e] += (pv == plo ? A : 0.f) + (pv == phi ? B : 0.f);
+  }
+}
+// losses[] patch-up after csmae_loss_finalize: the ssim term of each view joins (weight 0.1, the mse_* kinds) or replaces the
+// masked per-patch term
+__global__ void ssim_apply_kernel(int pure, int views, float weight, float recon_scale, const float* __restrict__ terms, float* __restrict__ losses) {
+  if (threadIdx.x != 0) return;
+  float add = 0.f, old = 0.f;
+  for (int v = 0; v < views; ++v) {
+    const float t = weight * terms[v];
+    if (pure) { old += losses[1 + v]; losses[1 + v] = t; } else losses[1 + v] += t;
+    add += t;
+  }
+  losses[0] = (pure ? losses[3] + losses[4] + losses[5] : losses[0]) + recon_scale * add;
+  (void)old;
+}
+
+extern "C" int csmae_ssim_workspace_floats(long long B2, int C, int S, int p, int levels, long long* floats) {
+  CSMAE_REQUIRE(B2 > 0 && C > 0 && S > 0 && p > 0 && S % p == 0 && (levels == 1 || levels == SSIM_MAX_LEVELS) && floats, "csmae_ssim_workspace_floats: bad args");
+  *floats = ssim_layout(B2, C, S, p, levels).total;
+  return CSMAE_OK;
+}
+extern "C" int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
+                              const float* pred, long long ldp, const float* mask, float* ws, float* terms, void* stream) {
+  CSMAE_REQUIRE(levels == 1 || levels == SSIM_MAX_LEVELS, "csmae_ssim_fwd: levels must be 1 (ssim) or 5 (ms_ssim)");
+  CSMAE_REQUIRE(B2 > 0 && N > 0 && B2 % N == 0 && B2 / N <= 2 && S % p == 0 && ws && terms && pred && img0, "csmae_ssim_fwd: bad args");
+  CSMAE_REQUIRE(S >= SSIM_WIN, "csmae_ssim_fwd: images smaller than the 11-tap window are not supported (S = %d)", S);
+  CSMAE_REQUIRE(levels == 1 || S > SSIM_R * 16, "csmae_ssim_fwd: Image size should be larger than 160 due to the 4 downsamplings in ms-ssim (S = %d)", S);
+  hipStream_t st = (hipStream_t)stream;
+  const PatchGeom g = make_geom(N, C, S, p);
+  const SsimLayout L = ssim_layout(B2, C, S, p, levels);
+  const SsimWin win = ssim_window();
+  const long long patches = B2 * g.L;
+  const int views = (int)(B2 / N);
+  float* stat = ws + L.stat; float* mm = ws + L.mm; float* mmout = ws + L.val;  // (val is free until the stats kernel)
+  hipLaunchKernelGGL(pred_minmax_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, patches, pred, ldp, mm);
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, st, (long long)N * g.L, views, mm, mmout);
+  hipLaunchKernelGGL(ssim_stat_store_kernel, dim3(1), dim3(64), 0, st, views, 0, mmout, stat);
+  hipLaunchKernelGGL(target_minmax_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, norm_pix, patches, img0, img1, mm);
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, st, (long long)N * g.L, views, mm, mmout);
+  hipLaunchKernelGGL(ssim_stat_store_kernel, dim3(1), dim3(64), 0, st, views, 1, mmout, stat);
+  hipLaunchKernelGGL(ssim_prepare_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, norm_pix, patches, img0, img1, pred, ldp, mask, stat, ws + L.X[0], ws + L.Y[0]);
+  SsimStatArgs sa; sa.levels = levels;
+  for (int l = 0; l < SSIM_MAX_LEVELS; ++l) { sa.tiles[l] = L.tiles[l]; sa.Ho[l] = L.Ho[l]; sa.part[l] = ws + L.part[l]; }
+  for (int l = 0; l < levels; ++l) {
+    const int tx = cdiv(L.Ho[l], SSIM_TILE);
+    hipLaunchKernelGGL(ssim_level_fwd_kernel, dim3(tx * tx, (unsigned)L.planes), dim3(256), 0, st, win, L.H[l], L.Ho[l], tx, ws + L.X[l], ws + L.Y[l], ws + L.part[l]);
+    if (l + 1 < levels)
+      hipLaunchKernelGGL(ssim_pool_kernel, dim3(cdiv(L.planes * L.H[l + 1] * L.H[l + 1], 256)), dim3(256), 0, st, L.planes, L.H[l], L.pad[l], L.H[l + 1],
+                         ws + L.X[l], ws + L.Y[l], ws + L.X[l + 1], ws + L.Y[l + 1]);
+  }
+  hipLaunchKernelGGL(ssim_stats_kernel, dim3(1), dim3(1024), 0, st, sa, L.planes, views, ws + L.coef, ws + L.val, terms);
+  return csmae_check_launch("csmae_ssim_fwd");
+}
+extern "C" int csmae_ssim_apply(int pure, int views, float weight, float recon_scale, const float* terms, float* losses, void* stream) {
+  CSMAE_REQUIRE((views == 1 || views == 2) && terms && losses, "csmae_ssim_apply: bad args");
+  hipLaunchKernelGGL(ssim_apply_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pure, views, weight, recon_scale, terms, losses);
+  return csmae_check_launch("csmae_ssim_apply");
+}
+extern "C" int csmae_ssim_bwd(int levels, long long B2, int N, int C, int S, int p, const float* pred, long long ldp, const float* mask,
+                              const float* gout, float scale, float* ws, float* extra, void* stream) {
+  CSMAE_REQUIRE(levels == 1 || levels == SSIM_MAX_LEVELS, "csmae_ssim_bwd: levels must be 1 (ssim) or 5 (ms_ssim)");
+  CSMAE_REQUIRE(B2 > 0 && N > 0 && B2 % N == 0 && B2 / N <= 2 && S % p == 0 && ws && extra && pred && gout, "csmae_ssim_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const PatchGeom g = make_geom(N, C, S, p);
+  const SsimLayout L = ssim_layout(B2, C, S, p, levels);
+  const SsimWin win = ssim_window();
+  const long long patches = B2 * g.L;
+  const int views = (int)(B2 / N);
+  for (int l = levels - 1; l >= 0; --l) {
+    const int tx = cdiv(L.H[l], SSIM_TILE);
+    const bool nxt = l + 1 < levels;
+    hipLaunchKernelGGL(ssim_level_bwd_kernel, dim3(tx * tx, (unsigned)L.planes), dim3(256), 0, st, win, L.H[l], L.Ho[l], tx, l, ws + L.X[l], ws + L.Y[l],
+                       ws + L.coef, nxt ? ws + L.D[l + 1] : nullptr, nxt ? L.H[l + 1] : 0, L.pad[l], ws + L.D[l]);
+  }
+  hipLaunchKernelGGL(ssim_pred_bwd_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, patches, pred, ldp, mask, ws + L.stat, ws + L.D[0], gout, scale, extra, ws + L.mm);
+  hipLaunchKernelGGL(ssim_tie_reduce_kernel, dim3(1), dim3(1024), 0, st, (long long)N * g.L, views, ws + L.mm, ws + L.stat);
+  hipLaunchKernelGGL(ssim_tie_apply_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, patches, pred, ldp, ws + L.stat, extra);
+  return csmae_check_launch("csmae_ssim_bwd");
 }
 
 // ------------------------------------------------------------------------------------------ scalar assembly

@@ -8,7 +8,7 @@ import torch.nn as nn
 from util.pos_embed import get_2d_sincos_pos_embed
 
 from ._holders import Block, PatchEmbed
-from .MAE_ViT_Shared import MAE_ViT_Shared
+from .MAE_ViT_Shared import SSIM_LOSSES, MAE_ViT_Shared
 
 
 class _StepFn(torch.autograd.Function):
@@ -35,6 +35,12 @@ class _StepFn(torch.autograd.Function):
             grads = [p.grad for p in model.parameters() if p.requires_grad]
             ctx.engine.backward(gloss, accumulate=any(g is not None for g in grads))
         return (None,) * 7
+
+
+def _check_ssim_geometry(C):
+    if C != 3:  # MAE_ViT_Shared.py:194-199: the mask is repeated for 3 channels and then un-patchified with input_channels
+        raise ValueError(f"the ssim family of losses needs input_channels == 3 (got {C}): the reference builds its pixel mask for 3 channels "
+                         "(MAE_ViT_Shared.py:194-196) and fails to reshape it otherwise")
 
 
 class MAE_ViT_Baseline(MAE_ViT_Shared):
@@ -132,6 +138,8 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
         dtype = self.compute_dtype
         if dtype is None:
             dtype = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        if self.loss in SSIM_LOSSES:
+            _check_ssim_geometry(self.input_channels)
         if dtype not in self._engines:
             self._engines[dtype] = Engine(self, self._flat, self._cfg(), dtype)
         eng = self._engines[dtype]
@@ -204,7 +212,7 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
     def forward_loss(self, imgs, pred, mask=None):
         """Reconstruction loss of `--loss` on patchified `imgs` (MAE_ViT_Shared.py:269-290) through the same fused HIP loss kernels
         `forward` uses (image read once, patchify / norm_pix / bce scaling inside the kernel).  Inference only."""
-        from csmae_hip import ops
+        from csmae_hip import SSIM_KINDS, ops
         N, L, P = pred.shape
         C, S, p = self.input_channels, self.input_size, self.patch_size
         imgs = imgs.contiguous().float()
@@ -214,11 +222,23 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
         full = full.view(N * (L + 1), P)
         rowloss = torch.empty(N * L, device=dev, dtype=torch.float32)
         mm = None
-        if self.loss == "bce":
+        m = torch.ones(N, L, device=dev, dtype=torch.float32) if mask is None else mask.to(torch.float32).contiguous()
+        kind, ssim = self.loss, SSIM_KINDS.get(self.loss)
+        if ssim is not None:  # MAE_ViT_Shared.py:165-267 (no mask = every patch compared, :187-189)
+            _check_ssim_geometry(C)
+            kind = ssim[0]
+            ws = torch.empty(ops.ssim_workspace_floats(N, C, S, p, ssim[1]), device=dev, dtype=torch.float32)
+            terms = torch.empty(2, device=dev, dtype=torch.float32)
+            ops.ssim_fwd(ssim[1], self.norm_pix_loss, imgs, None, full, m, ws, terms, N, N, C, S, p)
+        if kind == "bce":
             mm = torch.empty(2, device=dev, dtype=torch.float32)
             ops.target_minmax(imgs, None, torch.empty(N * L * 2, device=dev, dtype=torch.float32), mm, N, N, C, S, p, self.norm_pix_loss)
-        ops.recon_loss_fwd(self.loss, self.norm_pix_loss, imgs, None, full, mm, rowloss, N, N, C, S, p)
-        m = torch.ones(N, L, device=dev, dtype=torch.float32) if mask is None else mask.to(torch.float32).contiguous()
+        if kind == "none":
+            rowloss.zero_()
+        else:
+            ops.recon_loss_fwd(kind, self.norm_pix_loss, imgs, None, full, mm, rowloss, N, N, C, S, p)
         losses = torch.zeros(8, device=dev, dtype=torch.float32)
         ops.loss_finalize(N * L, 1, rowloss, m, 1.0, losses)
+        if ssim is not None:
+            ops.ssim_apply(kind == "none", 1, ssim[2], 1.0, terms, losses)
         return losses[1].clone()

@@ -9,6 +9,6 @@ class MAE_ViT_MsLdCd(MAE_ViT_MsLd):
 
     def __init__(self, loss_cd=None, predictor_hidden_size=2048, **kwargs):
         super().__init__(**kwargs)
-        self.loss_cd = check_loss(loss_cd, "loss_cd") if loss_cd is not None else self.loss
+        self.loss_cd = check_loss(loss_cd if loss_cd is not None else self.loss, "loss_cd")
         self.predictor_hidden_size = predictor_hidden_size
         self.predictor = MLP(self.decoder_embed_dim, self.num_patches, predictor_hidden_size)

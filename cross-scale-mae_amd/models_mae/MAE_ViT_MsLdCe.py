@@ -11,7 +11,7 @@ class MAE_ViT_MsLdCe(MAE_ViT_MsLd):
 
     def __init__(self, loss_ce=None, predictor_hidden_size=2048, **kwargs):
         super().__init__(**kwargs)
-        self.loss_ce = check_loss(loss_ce, "loss_ce") if loss_ce is not None else self.loss
+        self.loss_ce = check_loss(loss_ce if loss_ce is not None else self.loss, "loss_ce")
         self.predictor_hidden_size = predictor_hidden_size
         self.predictor = MLP(self.dim_model, self.num_patches, predictor_hidden_size)
 

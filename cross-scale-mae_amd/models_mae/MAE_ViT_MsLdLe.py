@@ -8,7 +8,7 @@ class MAE_ViT_MsLdLe(MAE_ViT_MsLd):
 
     def __init__(self, loss_e=None, **kwargs):
         super().__init__(**kwargs)
-        self.loss_e = check_loss(loss_e, "loss_e") if loss_e is not None else self.loss
+        self.loss_e = check_loss(loss_e if loss_e is not None else self.loss, "loss_e")
 
     def forward(self, imgs, mask_ratio=0.75, mask_seed: int = None, return_embeds=False, consistent_mask=False, targets=None):
         return self._forward_ms(imgs, mask_ratio, mask_seed, return_embeds, consistent_mask)

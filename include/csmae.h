@@ -104,7 +104,20 @@ int csmae_recon_loss_fwd(int kind, int norm_pix, long long B2, int N, int C, int
                          const float* pred, long long ldp, const float* minmax, float* rowloss, void* stream);
 int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, long long B2, int N, int C, int S, int p, const float* img0,
                          const float* img1, const float* pred, long long ldp, const float* minmax, const float* mask,
-                         const float* losses, const float* gout, float vscale, void* dpred, long long ldd, void* stream);
+                         const float* losses, const float* gout, float vscale, const float* extra, void* dpred, long long ldd,
+                         void* stream);
+/* ---- the ssim family of reconstruction losses: MAE_ViT_Shared.forward_loss_{ssim,ms_ssim} (:165-247) around
+ * pytorch-msssim 0.2.1 ssim / ms_ssim (:204,:247).  levels = 1 (ssim, nonnegative) or 5 (ms_ssim).  `ws` holds the image planes,
+ * partial sums and statistics between the calls (csmae_ssim_workspace_floats floats, caller-allocated, untouched between fwd and bwd).
+ * fwd: terms[v] = 1 - score of view v.   apply (after csmae_loss_finalize): losses[1+v] (+)= weight * terms[v], total fixed up
+ * (`pure` = no per-patch term, the plain ssim / ms_ssim kinds; otherwise the 0.1-weighted mse_* kinds :249-267).
+ * bwd: extra[B2*L][P] (fp32) = gout * scale * d terms / d pred, handed to csmae_recon_loss_bwd (kind 5 = no per-patch term). */
+int csmae_ssim_workspace_floats(long long B2, int C, int S, int p, int levels, long long* floats /* host pointer, out */);
+int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
+                   const float* pred, long long ldp, const float* mask, float* ws, float* terms, void* stream);
+int csmae_ssim_apply(int pure, int views, float weight, float recon_scale, const float* terms, float* losses, void* stream);
+int csmae_ssim_bwd(int levels, long long B2, int N, int C, int S, int p, const float* pred, long long ldp, const float* mask,
+                   const float* gout, float scale, float* ws, float* extra, void* stream);
 /* ---- un-masked `.mean()` losses: cross-decoder (MAE_ViT_MsLdCeCd.py:56-59, target NOT detached) and latent (MsLdLe.py:44) */
 int csmae_pair_loss_fwd(int kind, long long rows, int D, const float* a, long long a_group, long long a_gstride, long long a_off,
                         const float* t, long long t_group, long long t_gstride, long long t_off, float* partial, void* stream);

@@ -65,8 +65,12 @@ def test_constructor_surface():
     assert m.no_weight_decay() == {} and m.use_xformers is False and m.mask_ratio == 0.75
     x = torch.randn(2, 3, 64, 64)
     assert torch.equal(m.unpatchify(m.patchify(x, 16, 3), 16, 3), x)
-    with pytest.raises(NotImplementedError, match="SSIM"):
-        models_mae.mae_vit_base(input_size=64, loss="ssim")
+    assert models_mae.mae_vit_base(input_size=64, loss="ssim").loss == "ssim"   # §8 f-4: reconstruction loss only ...
+    with pytest.raises(ValueError, match="only serves the reconstruction loss"):  # ... the reference dies in forward (unpatchify(x, None, None))
+        models_mae.mae_vit_base_MsLdCeCd(input_size=64, loss="mse_ssim")          # loss_cd defaults to `loss` (MAE_ViT_MsLdCeCd.py:18)
+    assert models_mae.mae_vit_base_MsLdCeCd(input_size=64, loss="mse_ssim", loss_cd="mse").loss_cd == "mse"
+    with pytest.raises(AttributeError, match="forward_loss_huber"):
+        models_mae.mae_vit_base(input_size=64, loss="huber")
     with pytest.raises(NotImplementedError, match="xFormers"):
         models_mae.mae_vit_base(input_size=64, use_xformers=True)
     with pytest.raises(AssertionError):

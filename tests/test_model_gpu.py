@@ -162,6 +162,60 @@ def test_loss_options_fp32(loss):
     np.testing.assert_allclose(got, d[f"cecd_{loss}_gradsq"], rtol=5e-3, atol=1e-14)
 
 
+@pytest.mark.parametrize("variant,kind,S", [("MAE_ViT_MsLdCeCd", "mse_ssim", 64), ("MAE_ViT_MsLd", "ssim", 64),
+                                            ("MAE_ViT_Baseline", "ms_ssim", 176), ("MAE_ViT_MsLd", "mse_ms_ssim", 176)])
+def test_ssim_family_step_fp32(variant, kind, S):
+    """`--loss ssim / ms_ssim / mse_ssim / mse_ms_ssim` (MAE_ViT_Shared.py:165-267) through the whole step, against the
+    oracle's autograd on the same weights, noise and crop box: total loss within 1e-4, gradient norms within 5e-3."""
+    import models_mae
+    torch.manual_seed(5)
+    cd = dict(loss_cd="mse") if "Cd" in variant else {}
+    extra = dict(predictor_hidden_size=128, **cd) if "Cd" in variant else {}
+    m = getattr(models_mae, variant)(**MICRO, input_size=S, patch_size="16", loss=kind, **extra).cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    N, L = 2, (S // 16) ** 2
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randn(N, 3, S, S, generator=g)
+    base = variant == "MAE_ViT_Baseline"
+    dr = dict(noise=[torch.rand(N, L, generator=g)] + ([] if base else [torch.rand(N, L, generator=g)]),
+              box=None if base else (S // 12, S // 7, (S * 5) // 8, (S * 9) // 16))
+    m._test_draws = dict(dr)
+    out = m(imgs.cuda())
+    out[0].backward()
+    osd, oout = oracle_run(sd, variant[len("MAE_ViT_"):], imgs, dr, input_size=S, loss=kind, **cd)
+    assert rel(out[0], oout["loss"]) < LOSS_RTOL, (float(out[0]), float(oout["loss"]))
+    params = dict(m.named_parameters())
+    for name in ("decoder_pred.weight", "decoder_pred.bias", "decoder.1.mlp.fc2.weight", "encoder.0.attn.qkv.weight", "patch_embed.proj.weight", "mask_token"):
+        got, want = params[name].grad.double().cpu(), osd[name].grad.double()
+        assert abs(got.norm() - want.norm()) <= 5e-3 * want.norm(), name
+        assert (got - want).norm() <= 2e-2 * want.norm(), name
+
+
+def test_ssim_family_standalone_forward_loss_and_bf16_step():
+    import csmae_oracle as O
+    import models_mae
+    torch.manual_seed(6)
+    m = models_mae.MAE_ViT_Baseline(**MICRO, input_size=176, patch_size="16", loss="mse_ms_ssim").cuda().train()
+    g = torch.Generator().manual_seed(10)
+    imgs = torch.randn(2, 3, 176, 176, generator=g)
+    pred = 0.7 * O.patchify(imgs, 16, 3) + 0.4 * torch.randn(2, 121, 768, generator=g)
+    mask = (torch.rand(2, 121, generator=g) > 0.25).float()
+    tgt = O.recon_target(imgs, 16, 3, False)
+    for mk in (mask, None):
+        got = m.forward_loss(imgs.cuda(), pred.cuda(), None if mk is None else mk.cuda())
+        assert rel(got, O.loss_fn("mse_ms_ssim", tgt, pred, mk, 16, 3)) < LOSS_RTOL
+    m.compute_dtype = torch.bfloat16   # the MFMA path: same loss head in fp32 behind bf16 GEMMs
+    m32 = models_mae.MAE_ViT_Baseline(**MICRO, input_size=176, patch_size="16", loss="mse_ms_ssim").cuda().train()
+    m32.load_state_dict(m.state_dict())
+    noise = torch.rand(2, 121, generator=g)
+    m._test_draws, m32._test_draws = dict(noise=[noise], box=None), dict(noise=[noise], box=None)
+    a, b = m(imgs.cuda()), m32(imgs.cuda())
+    a[0].backward()
+    assert rel(a[0], b[0]) < 2e-2 and torch.isfinite(m.decoder_pred.weight.grad).all()
+    with pytest.raises(ValueError, match="input_channels == 3"):
+        models_mae.MAE_ViT_Baseline(**MICRO, input_size=64, patch_size="16", input_channels=4, loss="ssim").cuda()(torch.randn(2, 4, 64, 64).cuda())
+
+
 def test_bce_reconstruction_supported_but_bce_cross_decoder_is_not():
     import csmae_hip
     d = load("model_micro.npz")

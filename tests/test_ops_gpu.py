@@ -368,6 +368,87 @@ def test_recon_loss_fwd_bwd(ops, kind, norm_pix):
     assert_close(dpred, pr.grad, 1e-4, 1e-7, f"dpred {kind}")
 
 
+def _ssim_run(ops, kind, norm_pix, img0, img1, pred_rows, mask, p, g=0.7, vscale=1.0):
+    """Two views through csmae_ssim_fwd / loss_finalize / ssim_apply / ssim_bwd / recon_loss_bwd -> (losses[8], dpred rows)."""
+    from csmae_hip import SSIM_KINDS
+    base, levels, weight = SSIM_KINDS[kind]
+    N, C, S = img0.shape[0], img0.shape[1], img0.shape[2]
+    L, P = (S // p) ** 2, p * p * C
+    B2 = 2 * N
+    gp, gm = dev(pred_rows), dev(mask)
+    ws = torch.empty(ops.ssim_workspace_floats(B2, C, S, p, levels), device="cuda")
+    terms = torch.empty(2, device="cuda")
+    ops.ssim_fwd(levels, norm_pix, dev(img0), dev(img1), gp, gm, ws, terms, B2, N, C, S, p)
+    rowloss = torch.zeros(B2 * L, device="cuda")
+    if base != "none":
+        ops.recon_loss_fwd(base, norm_pix, dev(img0), dev(img1), gp, None, rowloss, B2, N, C, S, p)
+    losses = torch.zeros(8, device="cuda")
+    ops.loss_finalize(N * L, 2, rowloss, gm, vscale, losses)
+    ops.ssim_apply(base == "none", 2, weight, vscale, terms, losses)
+    gout = torch.tensor([g], device="cuda")
+    extra = torch.full((B2 * L, P), float("nan"), device="cuda")
+    ops.ssim_bwd(levels, gp, gm, gout, vscale * weight, ws, extra, B2, N, C, S, p)
+    dpred = torch.full((B2 * (L + 1), P), float("nan"), device="cuda")
+    ops.recon_loss_bwd(base, norm_pix, dev(img0), dev(img1), gp, None, gm, losses, gout, vscale, dpred, B2, N, C, S, p, extra=extra)
+    return losses, dpred
+
+
+@pytest.mark.parametrize("kind,S,p,norm_pix", [("ssim", 64, 16, False), ("mse_ssim", 64, 16, True), ("ssim", 48, 8, False),
+                                               ("ms_ssim", 176, 16, False), ("mse_ms_ssim", 168, 8, False), ("ms_ssim", 200, 8, True)])
+def test_ssim_family_fwd_bwd(ops, kind, S, p, norm_pix):
+    """MAE_ViT_Shared.forward_loss_{ssim,ms_ssim,mse_ssim,mse_ms_ssim} (:165-267), two views, against the oracle's
+    autograd.  200 / 8 -> 25 patches per side: levels 200, 100, 50, 25 (odd: padded pooling), 13.  Tolerance: fp32, 1e-4 on the
+    loss; the gradient within 2e-3 of its largest element (E[x^2] - mu^2 cancellations, different summation order)."""
+    import csmae_oracle as O
+    N, C = 2, 3
+    L, P = (S // p) ** 2, p * p * C
+    B2 = 2 * N
+    img0, img1 = rnd(N, C, S, S, seed=80), rnd(N, C, S, S, seed=81)
+    imgs = torch.cat([img0, img1])
+    pred_full = rnd(B2 * (L + 1), P, seed=82, scale=0.5)
+    pred_full.reshape(B2, L + 1, P)[:, 1:] += 0.7 * O.patchify(imgs, p, C)   # image-like: scores away from the relu clamps
+    mask = (torch.rand(B2, L, generator=torch.Generator().manual_seed(83)) > 0.3).float()
+    pr = pred_full.clone().requires_grad_(True)
+    pv = pr.reshape(B2, L + 1, P)[:, 1:]
+    lo = O.loss_fn(kind, O.recon_target(img0, p, C, norm_pix), pv[:N], mask[:N], p, C)
+    lc = O.loss_fn(kind, O.recon_target(img1, p, C, norm_pix), pv[N:], mask[N:], p, C)
+    g = 0.7
+    ((lo + lc) * 0.5 * g).backward()
+    losses, dpred = _ssim_run(ops, kind, norm_pix, img0, img1, pred_full, mask, p, g=g, vscale=0.5)
+    assert_close(losses[1:3], torch.stack([lo, lc]), 1e-4, 1e-6, f"recon {kind}")
+    assert_close(losses[0], 0.5 * (lo + lc), 1e-4, 1e-6, "total")
+    ref = pr.grad
+    assert torch.isfinite(dpred).all()
+    err = (dpred.cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+    assert dpred.reshape(B2, L + 1, P)[:, 0].abs().max().item() == 0.0   # cls rows
+
+
+@pytest.mark.parametrize("tag,kinds", [("s64", ("ssim", "mse_ssim")), ("s168", ("ms_ssim", "mse_ms_ssim"))])
+def test_ssim_family_golden(ops, tag, kinds):
+    """The committed fixture: the reference's own loss wiring around a float64 formulation of pytorch-msssim (oracle/gen_golden.py)."""
+    d = np.load(os.path.join(G, "ssim_loss.npz"))
+    imgs, pred, mask, p = torch.from_numpy(d[f"{tag}_imgs"]), torch.from_numpy(d[f"{tag}_pred"]), torch.from_numpy(d[f"{tag}_mask"]), int(d[f"{tag}_p"])
+    N, L, P = pred.shape
+    rows = torch.zeros(2 * N, L + 1, P)
+    rows[:N, 1:] = pred
+    rows[N:, 1:] = pred   # both "views" carry the fixture: each must reproduce it
+    for kind in kinds:
+        losses, dpred = _ssim_run(ops, kind, False, imgs, imgs, rows.reshape(-1, P), torch.cat([mask, mask]), p, g=1.0, vscale=1.0)
+        want = float(d[f"{tag}_{kind}_masked"])
+        assert_close(losses[1:3], torch.tensor([want, want]), 1e-4, 1e-6, f"golden {kind}")
+        ref = torch.from_numpy(d[f"{tag}_{kind}_masked_grad"])
+        for v in range(2):
+            got = dpred.reshape(2 * N, L + 1, P)[v * N:(v + 1) * N, 1:].cpu()
+            assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_ssim_rejects_what_the_reference_rejects(ops):
+    with pytest.raises(Exception, match="larger than 160"):
+        ws = torch.empty(768 * 1024, device="cuda")
+        ops.ssim_fwd(5, False, ws, ws, ws.reshape(-1, 768), None, ws, ws, 2, 1, 3, 64, 16)
+
+
 @pytest.mark.parametrize("kind", ["mse", "l2", "mae", "l1"])
 def test_pair_loss(ops, kind):
     import csmae_oracle as O
