@@ -27,12 +27,12 @@ GFLOP_PER_IMAGE = 118.80           # SURVEY.md §8(d), config 2, fwd + bwd (= 3 
 BATCH_PER_GPU, INPUT, PATCH = 128, 224, 16
 
 
-def build(device, batch, world):
+def build(device, batch, world, loss="mse"):
     import models_mae
     from csmae_hip.optim import FusedAdamW, add_weight_decay
     from csmae_hip.parallel import DataParallel
     torch.manual_seed(0)
-    model = models_mae.mae_vit_base_MsLdCeCd(input_size=INPUT, patch_size=str(PATCH), loss="mse", mask_ratio=0.75, device=str(device))
+    model = models_mae.mae_vit_base_MsLdCeCd(input_size=INPUT, patch_size=str(PATCH), loss=loss, loss_cd="mse", mask_ratio=0.75, device=str(device))
     model.to(device).train()
     model.compute_dtype = torch.bfloat16
     lr = 5e-5 * batch * world / 256  # main_pretrain.py:406-412 (blr 5e-5)
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (the headline metric is defined at 128)")
+    ap.add_argument("--loss", type=str, default="mse", help="reconstruction loss (the headline metric is defined with mse; e.g. mse_ssim, ms_ssim for SURVEY §8 f-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     import csmae_hip
     csmae_hip.load()
 
-    model, wrapped, opt = build(device, a.batch, world)
+    model, wrapped, opt = build(device, a.batch, world, a.loss)
     torch.manual_seed(0 + rank)  # main_pretrain.py:368
     samples = torch.randn(a.batch, 3, INPUT, INPUT, device=device)
 
@@ -172,13 +173,13 @@ def main():
     if rank == 0:
         ips = a.batch * world * a.steps / elapsed
         ach = ips / world * GFLOP_PER_IMAGE / 1e3  # TFLOP/s per GPU
-        scale = a.batch == BATCH_PER_GPU
+        scale = a.batch == BATCH_PER_GPU and a.loss == "mse"
         out = {
             "metric": "pretrain images/sec ViT-B/16 224^2 two-scale", "value": round(ips, 2), "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "MAE_ViT_MsLdCeCd ViT-B/16, 224^2 two-scale crops, mask 0.75, AdamW, full optimizer step",
-                       "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [3, INPUT, INPUT], "parallelism": f"dp{world}",
+                       "loss": a.loss, "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [3, INPUT, INPUT], "parallelism": f"dp{world}",
                        "headline_config": bool(scale)},
             "loss": round(final_loss, 5),
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),

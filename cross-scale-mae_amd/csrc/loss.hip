@@ -62,14 +62,16 @@ __global__ __launch_bounds__(256) void target_minmax_kernel(PatchGeom g, int nor
   lo = -wave_max(-lo); hi = wave_max(hi);
   if (lane == 0) { mm[pt * 2] = lo; mm[pt * 2 + 1] = hi; }
 }
-__global__ __launch_bounds__(256) void minmax_reduce_kernel(long long per_view, int views, const float* __restrict__ mm, float* __restrict__ out /*[views][2]*/) {
-  __shared__ float slo[256], shi[256];
+__global__ __launch_bounds__(1024) void minmax_reduce_kernel(long long per_view, int views, const float* __restrict__ mm, float* __restrict__ out /*[views][2]*/) {
+  __shared__ float slo[16], shi[16];
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int v = 0; v < views; ++v) {
     float lo = INFINITY, hi = -INFINITY;
     for (long long i = threadIdx.x; i < per_view; i += blockDim.x) { lo = fminf(lo, mm[(v * per_view + i) * 2]); hi = fmaxf(hi, mm[(v * per_view + i) * 2 + 1]); }
-    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi;
+    lo = -wave_max(-lo); hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { slo[w] = lo; shi[w] = hi; }
     __syncthreads();
-    if (threadIdx.x == 0) { for (int i = 1; i < 256; ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); } out[v * 2] = lo; out[v * 2 + 1] = hi; }
+    if (threadIdx.x == 0) { for (int i = 1; i < nw; ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); } out[v * 2] = lo; out[v * 2 + 1] = hi; }
     __syncthreads();
   }
 }
@@ -140,7 +142,7 @@ extern "C" int csmae_target_minmax(int norm_pix, long long B2, int N, int C, int
   PatchGeom g = make_geom(N, C, S, p);
   long long patches = B2 * g.L;
   hipLaunchKernelGGL(target_minmax_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, (hipStream_t)stream, g, norm_pix, patches, img0, img1, scratch);
-  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long long)N * g.L, (int)(B2 / N), scratch, out);
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long long)N * g.L, (int)(B2 / N), scratch, out);
   return csmae_check_launch("csmae_target_minmax");
 }
 extern "C" int csmae_recon_loss_fwd(int kind, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
@@ -447,49 +449,107 @@ __global__ __launch_bounds__(256) void ssim_pool_kernel(long long planes, int H,
 
 #define SSIM_C1 1.0e-4f   // (0.01 * data_range)^2, data_range = 1
 #define SSIM_C2 9.0e-4f   // (0.03 * data_range)^2
+// 11-tap FIR over a register window: four consecutive outputs from fourteen consecutive inputs (each LDS value is read once per
+// four outputs instead of once per tap).  Every element is a PAIR of independent signals (two adjacent columns in the passes along
+// H, two adjacent rows in the passes along W), so that the multiply-adds are gfx950's packed fp32 instructions: these kernels are
+// bound by VALU issue, not by HBM or LDS.
+__device__ __forceinline__ void fir4(const SsimWin& w, const f2_t (&in)[4 + SSIM_R], f2_t (&out)[4]) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    f2_t a = in[o] * w.w[0];
+#pragma unroll
+    for (int k = 1; k < SSIM_WIN; ++k) a += in[o + k] * w.w[k];
+    out[o] = a;
+  }
+}
+__device__ __forceinline__ f2_t rcp2(f2_t v) { return f2_t{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; }
+// stage a (rows x 2*pairs) window of two planes into LDS (zero outside the plane); 8-byte loads when the plane rows allow it
+template <int ROWS, int PAIRS, int STRIDE>
+__device__ __forceinline__ void ssim_stage(const float* __restrict__ px, const float* __restrict__ py, int H, int gy0, int gx0, float* sx, float* sy) {
+  const bool vec = (H & 1) == 0;   // gx0 is even: a pair is 8-byte aligned and lies inside or outside the plane as a whole
+  for (int i = threadIdx.x; i < ROWS * PAIRS; i += 256) {
+    const int r = i / PAIRS, cp = i - r * PAIRS, gy = gy0 + r, gx = gx0 + 2 * cp;
+    f2_t x = {0.f, 0.f}, y = {0.f, 0.f};
+    if (gy >= 0 && gy < H) {
+      if (vec) { if (gx >= 0 && gx < H) { x = *reinterpret_cast<const f2_t*>(px + (long long)gy * H + gx); y = *reinterpret_cast<const f2_t*>(py + (long long)gy * H + gx); } }
+      else {
+        if (gx >= 0 && gx < H) { x[0] = px[(long long)gy * H + gx]; y[0] = py[(long long)gy * H + gx]; }
+        if (gx + 1 >= 0 && gx + 1 < H) { x[1] = px[(long long)gy * H + gx + 1]; y[1] = py[(long long)gy * H + gx + 1]; }
+      }
+    }
+    *reinterpret_cast<f2_t*>(sx + r * STRIDE + 2 * cp) = x;
+    *reinterpret_cast<f2_t*>(sy + r * STRIDE + 2 * cp) = y;
+  }
+}
+// pass along H over staged planes: for NRG groups of four rows and NCP column pairs, the five filtered quantities
+// (x, y, x^2, y^2, xy) -> V[m][row][col]
+template <int NRG, int NCP, int SIN, int SOUT, int VROWS>
+__device__ __forceinline__ void ssim_pass_h(const SsimWin& win, const float* sx, const float* sy, float* V) {
+  for (int i = threadIdx.x; i < NRG * NCP; i += 256) {
+    const int rg = i / NCP, cp = i - rg * NCP;
+    f2_t x[4 + SSIM_R], y[4 + SSIM_R], t[4 + SSIM_R], o[4];
+#pragma unroll
+    for (int k = 0; k < 4 + SSIM_R; ++k) {
+      x[k] = *reinterpret_cast<const f2_t*>(sx + (rg * 4 + k) * SIN + 2 * cp);
+      y[k] = *reinterpret_cast<const f2_t*>(sy + (rg * 4 + k) * SIN + 2 * cp);
+    }
+    auto put = [&](int m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f2_t*>(V + (m * VROWS + rg * 4 + j) * SOUT + 2 * cp) = o[j];
+    };
+    fir4(win, x, o); put(0);
+    fir4(win, y, o); put(1);
+#pragma unroll
+    for (int k = 0; k < 4 + SSIM_R; ++k) t[k] = x[k] * x[k];
+    fir4(win, t, o); put(2);
+#pragma unroll
+    for (int k = 0; k < 4 + SSIM_R; ++k) t[k] = y[k] * y[k];
+    fir4(win, t, o); put(3);
+#pragma unroll
+    for (int k = 0; k < 4 + SSIM_R; ++k) t[k] = x[k] * y[k];
+    fir4(win, t, o); put(4);
+  }
+}
+// pass along W for one (row pair rp, column group c0): NM maps of V -> f[m][4] (element = the two rows)
+template <int NM, int SV, int VROWS>
+__device__ __forceinline__ void ssim_pass_w(const SsimWin& win, const float* V, int rp, int c0, f2_t (&f)[NM][4]) {
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    f2_t in[4 + SSIM_R];
+    const float* v0 = V + (m * VROWS + 2 * rp) * SV + c0;
+#pragma unroll
+    for (int k = 0; k < 4 + SSIM_R; ++k) in[k] = f2_t{v0[k], v0[SV + k]};
+    fir4(win, in, f[m]);
+  }
+}
 // One 32x32 tile of the SSIM / contrast-structure maps of one plane -> part[plane][tile] = (sum ssim_map, sum cs_map)
 __global__ __launch_bounds__(256) void ssim_level_fwd_kernel(SsimWin win, int H, int Ho, int tiles_x, const float* __restrict__ X, const float* __restrict__ Y,
                                                              float* __restrict__ part) {
-  constexpr int T = SSIM_TILE, E = T + SSIM_R, ES = E + 1;
-  __shared__ float sx[E * ES], sy[E * ES], V[5][T * ES], red[32];
+  constexpr int T = SSIM_TILE, E = T + SSIM_R, ES = 44;  // 42 staged rows / columns, row stride 44 floats
+  __shared__ __attribute__((aligned(16))) float sx[E * ES], sy[E * ES], V[5 * T * ES];
+  __shared__ float red[32];
   const long long pl = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, y0 = ty * T, x0 = tx * T;
-  const float* px = X + pl * H * H; const float* py = Y + pl * H * H;
-  for (int i = threadIdx.x; i < E * E; i += 256) {
-    const int r = i / E, c = i - r * E, gy = y0 + r, gx = x0 + c;
-    const bool ok = gy < H && gx < H;
-    sx[r * ES + c] = ok ? px[gy * H + gx] : 0.f;
-    sy[r * ES + c] = ok ? py[gy * H + gx] : 0.f;
-  }
+  ssim_stage<E, E / 2, ES>(X + pl * H * H, Y + pl * H * H, H, y0, x0, sx, sy);
   __syncthreads();
-  for (int i = threadIdx.x; i < T * E; i += 256) {  // along H
-    const int r = i / E, c = i - r * E;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-#pragma unroll
-    for (int k = 0; k < SSIM_WIN; ++k) {
-      const float x = sx[(r + k) * ES + c], y = sy[(r + k) * ES + c], w = win.w[k];
-      a0 += w * x; a1 += w * y; a2 += w * (x * x); a3 += w * (y * y); a4 += w * (x * y);
-    }
-    V[0][r * ES + c] = a0; V[1][r * ES + c] = a1; V[2][r * ES + c] = a2; V[3][r * ES + c] = a3; V[4][r * ES + c] = a4;
-  }
+  ssim_pass_h<T / 4, E / 2, ES, ES, T>(win, sx, sy, V);
   __syncthreads();
   float ss = 0.f, sc = 0.f;
-  for (int i = threadIdx.x; i < T * T; i += 256) {  // along W
-    const int r = i / T, c = i - r * T;
-    if (y0 + r >= Ho || x0 + c >= Ho) continue;
-    float f[5];
+  if (threadIdx.x < (T / 2) * (T / 4)) {  // 16 row pairs x 8 column groups
+    const int rp = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    f2_t f[5][4];
+    ssim_pass_w<5, ES, T>(win, V, rp, c0, f);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * V[q][r * ES + c + k];
-      f[q] = a;
+    for (int j = 0; j < 4; ++j) {
+      const f2_t mu1 = f[0][j], mu2 = f[1][j], m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
+      const f2_t s1 = f[2][j] - m11, s2 = f[3][j] - m22, s12 = f[4][j] - m12;
+      const f2_t cs = (s12 * 2.f + SSIM_C2) * rcp2(s1 + s2 + SSIM_C2);
+      const f2_t sm = (m12 * 2.f + SSIM_C1) * rcp2(m11 + m22 + SSIM_C1) * cs;
+      if (x0 + c0 + j < Ho) {
+        if (y0 + 2 * rp < Ho) { ss += sm[0]; sc += cs[0]; }
+        if (y0 + 2 * rp + 1 < Ho) { ss += sm[1]; sc += cs[1]; }
+      }
     }
-    const float mu1 = f[0], mu2 = f[1], m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
-    const float s1 = f[2] - m11, s2 = f[3] - m22, s12 = f[4] - m12;
-    const float cs = (2.f * s12 + SSIM_C2) / (s1 + s2 + SSIM_C2);
-    ss += ((2.f * m12 + SSIM_C1) / (m11 + m22 + SSIM_C1)) * cs;
-    sc += cs;
   }
   ss = block_sum(ss, red); sc = block_sum(sc, red);
   if (threadIdx.x == 0) { part[(pl * gridDim.x + blockIdx.x) * 2] = ss; part[(pl * gridDim.x + blockIdx.x) * 2 + 1] = sc; }
@@ -499,39 +559,49 @@ __global__ __launch_bounds__(256) void ssim_level_fwd_kernel(SsimWin win, int H,
 // ssim: relu(mean) per plane (nonnegative_ssim), averaged.  ms_ssim: prod_l relu(.)^w_l with cs for l < 4 and ssim for l = 4; a
 // clamped factor zeroes the product and (threshold backward selects 0) every gradient of that plane.
 struct SsimStatArgs { int levels, tiles[SSIM_MAX_LEVELS], Ho[SSIM_MAX_LEVELS]; const float* part[SSIM_MAX_LEVELS]; };
-__global__ __launch_bounds__(1024) void ssim_stats_kernel(SsimStatArgs a, long long planes, int views, float* __restrict__ coef, float* __restrict__ val,
-                                                          float* __restrict__ terms) {
-  __shared__ float red[32];
+__global__ __launch_bounds__(256) void ssim_stats_kernel(SsimStatArgs a, long long planes, int views, float* __restrict__ coef, float* __restrict__ val) {
   const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
   const long long per_view = planes / views;
-  for (long long pl = threadIdx.x; pl < planes; pl += blockDim.x) {
-    float ms[SSIM_MAX_LEVELS], mc[SSIM_MAX_LEVELS];
-    for (int l = 0; l < a.levels; ++l) {
+  // one wave per plane: the tile partials of a level are summed across the lanes (fixed order: deterministic)
+  const long long pl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (pl >= planes) return;
+  float ms[SSIM_MAX_LEVELS], mc[SSIM_MAX_LEVELS];
+#pragma unroll
+  for (int l = 0; l < SSIM_MAX_LEVELS; ++l) {
+    ms[l] = mc[l] = 0.f;
+    if (l < a.levels) {
       float s = 0.f, c = 0.f;
-      for (int t = 0; t < a.tiles[l]; ++t) { s += a.part[l][(pl * a.tiles[l] + t) * 2]; c += a.part[l][(pl * a.tiles[l] + t) * 2 + 1]; }
+      for (int t = lane; t < a.tiles[l]; t += 64) { s += a.part[l][(pl * a.tiles[l] + t) * 2]; c += a.part[l][(pl * a.tiles[l] + t) * 2 + 1]; }
       const float inv = 1.f / ((float)a.Ho[l] * a.Ho[l]);
-      ms[l] = s * inv; mc[l] = c * inv;
+      ms[l] = wave_sum(s) * inv; mc[l] = wave_sum(c) * inv;
     }
-    float* cf = coef + pl * SSIM_MAX_LEVELS * 2;
-    for (int l = 0; l < SSIM_MAX_LEVELS * 2; ++l) cf[l] = 0.f;
-    const float base = -1.f / (float)per_view;
-    float v;
-    if (a.levels == 1) {
-      v = fmaxf(ms[0], 0.f);
-      cf[0] = ms[0] > 0.f ? base / ((float)a.Ho[0] * a.Ho[0]) : 0.f;
-    } else {
-      float t[SSIM_MAX_LEVELS]; bool pos = true;
-      v = 1.f;
-      for (int l = 0; l < a.levels; ++l) { t[l] = fmaxf(l == a.levels - 1 ? ms[l] : mc[l], 0.f); pos &= t[l] > 0.f; v *= powf(t[l], wts[l]); }
-      if (!pos) v = 0.f;
-      for (int l = 0; l < a.levels; ++l) {
-        const float d = pos ? base * wts[l] * v / t[l] / ((float)a.Ho[l] * a.Ho[l]) : 0.f;
-        cf[l * 2 + (l == a.levels - 1 ? 0 : 1)] = d;
-      }
-    }
-    val[pl] = v;
   }
-  __syncthreads();
+  if (lane != 0) return;
+  float cf[SSIM_MAX_LEVELS * 2];
+#pragma unroll
+  for (int l = 0; l < SSIM_MAX_LEVELS * 2; ++l) cf[l] = 0.f;
+  const float base = -1.f / (float)per_view;
+  float v;
+  if (a.levels == 1) {
+    v = fmaxf(ms[0], 0.f);
+    cf[0] = ms[0] > 0.f ? base / ((float)a.Ho[0] * a.Ho[0]) : 0.f;
+  } else {
+    float t[SSIM_MAX_LEVELS]; bool pos = true;
+    v = 1.f;
+#pragma unroll
+    for (int l = 0; l < SSIM_MAX_LEVELS; ++l) { t[l] = fmaxf(l == SSIM_MAX_LEVELS - 1 ? ms[l] : mc[l], 0.f); pos &= t[l] > 0.f; v *= powf(t[l], wts[l]); }
+    if (!pos) v = 0.f;
+#pragma unroll
+    for (int l = 0; l < SSIM_MAX_LEVELS; ++l)
+      cf[l * 2 + (l == SSIM_MAX_LEVELS - 1 ? 0 : 1)] = pos ? base * wts[l] * v / t[l] / ((float)a.Ho[l] * a.Ho[l]) : 0.f;
+  }
+#pragma unroll
+  for (int l = 0; l < SSIM_MAX_LEVELS * 2; ++l) coef[pl * SSIM_MAX_LEVELS * 2 + l] = cf[l];
+  val[pl] = v;
+}
+__global__ __launch_bounds__(1024) void ssim_terms_kernel(long long per_view, int views, const float* __restrict__ val, float* __restrict__ terms) {
+  __shared__ float red[32];
   for (int vw = 0; vw < views; ++vw) {
     float s = 0.f;
     for (long long i = threadIdx.x; i < per_view; i += blockDim.x) s += val[vw * per_view + i];
@@ -546,83 +616,77 @@ __global__ __launch_bounds__(1024) void ssim_stats_kernel(SsimStatArgs a, long l
 __global__ __launch_bounds__(256) void ssim_level_bwd_kernel(SsimWin win, int H, int Ho, int tiles_x, int lvl, const float* __restrict__ X,
                                                              const float* __restrict__ Y, const float* __restrict__ coef,
                                                              const float* __restrict__ Dn, int Hn, int pad, float* __restrict__ D) {
-  constexpr int T = SSIM_TILE, E1 = T + SSIM_R, E2 = T + 2 * SSIM_R, S1 = E1 + 1, S2 = E2 + 1;
-  __shared__ float sxy[2 * E2 * S2];       // X | Y over the 52x52 halo region, later G[3][42][43]
-  __shared__ float V[5 * E1 * S2];         // H-filtered quantities [5][42][53], later T[3][32][43]
-  static_assert(3 * E1 * S1 <= 2 * E2 * S2 && 3 * T * S1 <= 5 * E1 * S2, "aliases fit");
+  // window positions q of this tile: 42 x 42 (q = p - 10 .. p), padded to 44 so that every pass works on groups of four
+  constexpr int T = SSIM_TILE, E1P = 44, E2 = E1P + SSIM_R, S2 = 56, S1 = 44;
+  __shared__ __attribute__((aligned(16))) float sxy[2 * E2 * S2];  // X | Y over the 54 x 54 halo region, later G[3][44][44]
+  __shared__ __attribute__((aligned(16))) float V[5 * E1P * S2];   // H-filtered quantities [5][44][56], later Tt[3][32][44]
+  static_assert(3 * E1P * S1 <= 2 * E2 * S2 && 3 * T * S1 <= 5 * E1P * S2, "aliases fit");
   float* sx = sxy; float* sy = sxy + E2 * S2;
   const long long pl = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x, y0 = ty * T, x0 = tx * T;
   const float* px = X + pl * H * H; const float* py = Y + pl * H * H;
   const float ca = coef[pl * SSIM_MAX_LEVELS * 2 + lvl * 2], cb = coef[pl * SSIM_MAX_LEVELS * 2 + lvl * 2 + 1];
-  for (int i = threadIdx.x; i < E2 * E2; i += 256) {
-    const int r = i / E2, c = i - r * E2, gy = y0 - SSIM_R + r, gx = x0 - SSIM_R + c;
-    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < H;
-    sx[r * S2 + c] = ok ? px[gy * H + gx] : 0.f;
-    sy[r * S2 + c] = ok ? py[gy * H + gx] : 0.f;
-  }
+  ssim_stage<E2, E2 / 2, S2>(px, py, H, y0 - SSIM_R, x0 - SSIM_R, sx, sy);
   __syncthreads();
-  for (int i = threadIdx.x; i < E1 * E2; i += 256) {  // along H: window rows q = y0 - 10 + r
-    const int r = i / E2, c = i - r * E2;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-#pragma unroll
-    for (int k = 0; k < SSIM_WIN; ++k) {
-      const float x = sx[(r + k) * S2 + c], y = sy[(r + k) * S2 + c], w = win.w[k];
-      a0 += w * x; a1 += w * y; a2 += w * (x * x); a3 += w * (y * y); a4 += w * (x * y);
-    }
-    V[(0 * E1 + r) * S2 + c] = a0; V[(1 * E1 + r) * S2 + c] = a1; V[(2 * E1 + r) * S2 + c] = a2; V[(3 * E1 + r) * S2 + c] = a3; V[(4 * E1 + r) * S2 + c] = a4;
-  }
+  ssim_pass_h<E1P / 4, E2 / 2, S2, S2, E1P>(win, sx, sy, V);   // window rows q = y0 - 10 + r
   __syncthreads();
   float* G = sxy;
-  for (int i = threadIdx.x; i < E1 * E1; i += 256) {  // along W, then the three coefficient maps
-    const int r = i / E1, c = i - r * E1, qy = y0 - SSIM_R + r, qx = x0 - SSIM_R + c;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (qy >= 0 && qy < Ho && qx >= 0 && qx < Ho) {
-      float f[5];
+  if (threadIdx.x < (E1P / 2) * (E1P / 4)) {  // 22 row pairs x 11 column groups: along W, then the three coefficient maps
+    const int rp = threadIdx.x / (E1P / 4), c0 = (threadIdx.x - rp * (E1P / 4)) * 4, qy = y0 - SSIM_R + 2 * rp;
+    f2_t f[5][4];
+    ssim_pass_w<5, S2, E1P>(win, V, rp, c0, f);
+    const bool oky0 = qy >= 0 && qy < Ho, oky1 = qy + 1 >= 0 && qy + 1 < Ho;
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * V[(q * E1 + r) * S2 + c + k];
-        f[q] = a;
-      }
-      const float mu1 = f[0], mu2 = f[1], m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
-      const float s1 = f[2] - m11, s2 = f[3] - m22, s12 = f[4] - m12;
-      const float B1 = m11 + m22 + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
-      const float lum = (2.f * m12 + SSIM_C1) / B1, cs = (2.f * s12 + SSIM_C2) / B2;
-      const float cc = ca * lum + cb;
-      g1 = -cc * cs / B2;
-      g2 = 2.f * cc / B2;
-      g0 = ca * cs * (2.f * mu2 - 2.f * lum * mu1) / B1 - 2.f * mu1 * g1 - mu2 * g2;
+    for (int j = 0; j < 4; ++j) {
+      const int qx = x0 - SSIM_R + c0 + j;
+      const f2_t mu1 = f[0][j], mu2 = f[1][j], m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
+      const f2_t s1 = f[2][j] - m11, s2 = f[3][j] - m22, s12 = f[4][j] - m12;
+      const f2_t rB1 = rcp2(m11 + m22 + SSIM_C1), rB2 = rcp2(s1 + s2 + SSIM_C2);
+      const f2_t lum = (m12 * 2.f + SSIM_C1) * rB1, cs = (s12 * 2.f + SSIM_C2) * rB2;
+      const f2_t cc = lum * ca + cb;
+      f2_t g1 = -cc * cs * rB2;
+      f2_t g2 = cc * rB2 * 2.f;
+      f2_t g0 = cs * (mu2 - lum * mu1) * rB1 * (2.f * ca) - mu1 * g1 * 2.f - mu2 * g2;
+      const bool okx = qx >= 0 && qx < Ho;
+      if (!(okx && oky0)) { g0[0] = 0.f; g1[0] = 0.f; g2[0] = 0.f; }
+      if (!(okx && oky1)) { g0[1] = 0.f; g1[1] = 0.f; g2[1] = 0.f; }
+      float* g = G + (2 * rp) * S1 + c0 + j;
+      g[0] = g0[0]; g[S1] = g0[1];
+      g[E1P * S1] = g1[0]; g[E1P * S1 + S1] = g1[1];
+      g[2 * E1P * S1] = g2[0]; g[2 * E1P * S1 + S1] = g2[1];
     }
-    G[(0 * E1 + r) * S1 + c] = g0; G[(1 * E1 + r) * S1 + c] = g1; G[(2 * E1 + r) * S1 + c] = g2;
   }
   __syncthreads();
   float* Tt = V;
-  for (int i = threadIdx.x; i < 3 * T * E1; i += 256) {  // transposed filter along H: rows p = y0 + r take windows q = p - k
-    const int m = i / (T * E1), j = i - m * T * E1, r = j / E1, c = j - r * E1;
-    float a = 0.f;
+  for (int i = threadIdx.x; i < 3 * (T / 4) * (E1P / 2); i += 256) {  // transposed filter along H: pixel rows p = y0 + r take windows q = p - k
+    const int m = i / ((T / 4) * (E1P / 2)), j = i - m * (T / 4) * (E1P / 2), rg = j / (E1P / 2), cp = j - rg * (E1P / 2);
+    f2_t in[4 + SSIM_R], o[4];
 #pragma unroll
-    for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * G[(m * E1 + r + SSIM_R - k) * S1 + c];
-    Tt[(m * T + r) * S1 + c] = a;
+    for (int k = 0; k < 4 + SSIM_R; ++k) in[k] = *reinterpret_cast<const f2_t*>(G + (m * E1P + rg * 4 + k) * S1 + 2 * cp);   // (symmetric window: G rows r .. r + 10 of pixel row r)
+    fir4(win, in, o);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f2_t*>(Tt + (m * T + rg * 4 + jj) * S1 + 2 * cp) = o[jj];
   }
   __syncthreads();
-  float* pd = D + pl * H * H;
-  const float* pn = Dn ? Dn + pl * Hn * Hn : nullptr;
-  for (int i = threadIdx.x; i < T * T; i += 256) {
-    const int r = i / T, c = i - r * T, gy = y0 + r, gx = x0 + c;
-    if (gy >= H || gx >= H) continue;
-    float o[3];
+  if (threadIdx.x < (T / 2) * (T / 4)) {
+    float* pd = D + pl * H * H;
+    const float* pn = Dn ? Dn + pl * Hn * Hn : nullptr;
+    const int rp = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    f2_t o[3][4];
+    ssim_pass_w<3, S1, T>(win, Tt, rp, c0, o);
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      float a = 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const int gy = y0 + 2 * rp + h;
+      if (gy >= H) continue;
 #pragma unroll
-      for (int k = 0; k < SSIM_WIN; ++k) a += win.w[k] * Tt[(m * T + r) * S1 + c + SSIM_R - k];
-      o[m] = a;
+      for (int j = 0; j < 4; ++j) {
+        const int gx = x0 + c0 + j;
+        if (gx >= H) continue;
+        float d = o[0][j][h] + 2.f * px[(long long)gy * H + gx] * o[1][j][h] + py[(long long)gy * H + gx] * o[2][j][h];
+        if (pn) { const int yy = (gy + pad) >> 1, xx = (gx + pad) >> 1; if (yy < Hn && xx < Hn) d += 0.25f * pn[yy * Hn + xx]; }
+        pd[(long long)gy * H + gx] = d;
+      }
     }
-    float d = o[0] + 2.f * px[gy * H + gx] * o[1] + py[gy * H + gx] * o[2];
-    if (pn) { const int yy = (gy + pad) >> 1, xx = (gx + pad) >> 1; if (yy < Hn && xx < Hn) d += 0.25f * pn[yy * Hn + xx]; }
-    pd[gy * H + gx] = d;
   }
 }
 // extra[pt][e] = gout * scale * dX0 * mask / range  (d loss / d pred through the scaled value), per-patch partial sums of the two
@@ -711,10 +775,10 @@ extern "C" int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int
   const int views = (int)(B2 / N);
   float* stat = ws + L.stat; float* mm = ws + L.mm; float* mmout = ws + L.val;  // (val is free until the stats kernel)
   hipLaunchKernelGGL(pred_minmax_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, patches, pred, ldp, mm);
-  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, st, (long long)N * g.L, views, mm, mmout);
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(1024), 0, st, (long long)N * g.L, views, mm, mmout);
   hipLaunchKernelGGL(ssim_stat_store_kernel, dim3(1), dim3(64), 0, st, views, 0, mmout, stat);
   hipLaunchKernelGGL(target_minmax_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, norm_pix, patches, img0, img1, mm);
-  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(256), 0, st, (long long)N * g.L, views, mm, mmout);
+  hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(1024), 0, st, (long long)N * g.L, views, mm, mmout);
   hipLaunchKernelGGL(ssim_stat_store_kernel, dim3(1), dim3(64), 0, st, views, 1, mmout, stat);
   hipLaunchKernelGGL(ssim_prepare_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, norm_pix, patches, img0, img1, pred, ldp, mask, stat, ws + L.X[0], ws + L.Y[0]);
   SsimStatArgs sa; sa.levels = levels;
@@ -726,7 +790,8 @@ extern "C" int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int
       hipLaunchKernelGGL(ssim_pool_kernel, dim3(cdiv(L.planes * L.H[l + 1] * L.H[l + 1], 256)), dim3(256), 0, st, L.planes, L.H[l], L.pad[l], L.H[l + 1],
                          ws + L.X[l], ws + L.Y[l], ws + L.X[l + 1], ws + L.Y[l + 1]);
   }
-  hipLaunchKernelGGL(ssim_stats_kernel, dim3(1), dim3(1024), 0, st, sa, L.planes, views, ws + L.coef, ws + L.val, terms);
+  hipLaunchKernelGGL(ssim_stats_kernel, dim3(cdiv(L.planes, 4)), dim3(256), 0, st, sa, L.planes, views, ws + L.coef, ws + L.val);
+  hipLaunchKernelGGL(ssim_terms_kernel, dim3(1), dim3(1024), 0, st, L.planes / views, views, ws + L.val, terms);
   return csmae_check_launch("csmae_ssim_fwd");
 }
 extern "C" int csmae_ssim_apply(int pure, int views, float weight, float recon_scale, const float* terms, float* losses, void* stream) {
