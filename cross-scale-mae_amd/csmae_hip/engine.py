@@ -368,14 +368,19 @@ class Engine:
             self.aux = torch.cuda.Stream()
         ce_done = None
 
-        def trunk(b0, nb, st, stream_obj):
-            """Encoder -> decoder -> prediction for samples [b0, b0 + nb).  Returns the event after the encoder (contrastive branch)."""
+        def trunk(b0, nb, st, stream_obj, evs):
+            """Encoder -> decoder -> prediction for samples [b0, b0 + nb), as a generator that yields after every block so that the
+            trunks of several streams are enqueued round-robin (a stream whose kernels are enqueued only after another stream's
+            whole trunk starts late whenever the host is not far ahead of the GPU).  Appends the event after the encoder (contrastive
+            branch) to `evs`."""
             for i in range(c["Ne"]):
                 self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, b0, nb, st)
+                yield
             ev = None
             if self.has_ce and ops._timer is None:
                 ev = torch.cuda.Event()
                 ev.record(stream_obj)
+            evs.append(ev)
             re_, rd_ = slice(b0 * Te, (b0 + nb) * Te), slice(b0 * Td, (b0 + nb) * Td)
             if self.T == BF16:
                 ops.cast_bf16(latent[re_], ws.lat_lp[re_], st=st)
@@ -385,12 +390,13 @@ class Engine:
             ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z[re_], bias=P("decoder_embed.bias"), st=st)
             ops.unshuffle_fwd(ws.z[re_], P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore[b0:b0 + nb],
                               ws.dec["x"][0][rd_], nb, L, keep, st=st)
+            yield
             for i in range(c["Nd"]):
                 self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, b0, nb, st)
+                yield
             ops.layernorm_fwd(ws.dec["x"][c["Nd"]][rd_], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp[rd_], ws.dn_st[0][rd_],
                               ws.dn_st[1][rd_], y32=ws.emb32[rd_], st=st)
             ops.gemm(ws.emb_lp[rd_], self._w_pred()[: c["P"]], ws.pred[rd_], bias=P("decoder_pred.bias"), st=st)
-            return ev
 
         if two:
             # The two views are independent until the losses: view 1 runs on the second stream.  Its kernels fill the CUs that view
@@ -403,10 +409,16 @@ class Engine:
             per = B2 // nch
             for so in self._fwd_streams[: nch - 1]:
                 so.wait_stream(main)         # (the stem; and the previous step's readers of the workspace)
-            evs = [trunk(0, per, st, main)]
-            for k in range(1, nch):
-                so = self._fwd_streams[k - 1]
-                evs.append(trunk(k * per, per, so.cuda_stream, so))
+            evs = []
+            gens = [trunk(0, per, st, main, evs)] + [trunk(k * per, per, self._fwd_streams[k - 1].cuda_stream, self._fwd_streams[k - 1], evs)
+                                                      for k in range(1, nch)]
+            if os.environ.get("CSMAE_FWD_SEQ_ENQUEUE"):  # tuning aid: one trunk after the other, as before
+                for g in gens:
+                    for _ in g:
+                        pass
+                gens = []
+            while gens:
+                gens = [g for g in gens if next(g, StopIteration) is not StopIteration]
             if self.has_ce:
                 self.aux.wait_stream(main)  # (workspace reuse: the previous step's backward read E / zc on the main stream)
                 for ev in evs:
@@ -417,7 +429,10 @@ class Engine:
             for so in self._fwd_streams[: nch - 1]:
                 main.wait_stream(so)
         else:
-            ev0 = trunk(0, B2, st, main)
+            evs = []
+            for _ in trunk(0, B2, st, main, evs):
+                pass
+            ev0 = evs[0]
             if self.has_ce:
                 if ev0 is None:
                     ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
