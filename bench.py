@@ -27,12 +27,24 @@ GFLOP_PER_IMAGE = 118.80           # SURVEY.md §8(d), config 2, fwd + bwd (= 3 
 BATCH_PER_GPU, INPUT, PATCH = 128, 224, 16
 
 
-def build(device, batch, world, loss="mse"):
+# the other BASELINE.json configs, as single-GPU slices (`--preset`; never the headline line): name -> (factory, input, patch, channels,
+# per-GPU batch, algorithmic GFLOP per image fwd+bwd from SURVEY.md §8d)
+PRESETS = {
+    "base": ("mae_vit_base_MsLdCeCd", 224, 16, 3, 128, 118.80),
+    "large": ("mae_vit_large_MsLdCeCd", 224, 16, 3, 128, 250.15),       # configs[2]: ViT-L/16 224^2, 128 per GPU
+    "large4": ("mae_vit_large_MsLdCeCd", 256, 16, 4, 128, 328.20),      # configs[3]: ViT-L/16 256^2 4-band
+    "huge14": ("mae_vit_huge_MsLdCeCd", 224, 14, 3, 256, 584.23),       # configs[4] geometry (ViT-H/14, 256 per GPU) with bf16 GEMMs
+}
+
+
+def build(device, batch, world, loss="mse", preset="base"):
     import models_mae
     from csmae_hip.optim import FusedAdamW, add_weight_decay
     from csmae_hip.parallel import DataParallel
     torch.manual_seed(0)
-    model = models_mae.mae_vit_base_MsLdCeCd(input_size=INPUT, patch_size=str(PATCH), loss=loss, loss_cd="mse", mask_ratio=0.75, device=str(device))
+    factory, size, patch, chans = PRESETS[preset][:4]
+    model = getattr(models_mae, factory)(input_size=size, patch_size=str(patch), input_channels=chans, loss=loss, loss_cd="mse", mask_ratio=0.75,
+                                         device=str(device))
     model.to(device).train()
     model.compute_dtype = torch.bfloat16
     lr = 5e-5 * batch * world / 256  # main_pretrain.py:406-412 (blr 5e-5)
@@ -91,7 +103,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (the headline metric is defined at 128)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (the headline metric is defined at 128)")
+    ap.add_argument("--preset", type=str, default="base", choices=list(PRESETS), help="single-GPU slice of another BASELINE.json config (not the headline)")
     ap.add_argument("--loss", type=str, default="mse", help="reconstruction loss (the headline metric is defined with mse; e.g. mse_ssim, ms_ssim for SURVEY §8 f-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -110,9 +123,12 @@ def main():
     import csmae_hip
     csmae_hip.load()
 
-    model, wrapped, opt = build(device, a.batch, world, a.loss)
+    factory, size, patch, chans, pbatch, gflop = PRESETS[a.preset]
+    if a.batch is None:
+        a.batch = pbatch
+    model, wrapped, opt = build(device, a.batch, world, a.loss, a.preset)
     torch.manual_seed(0 + rank)  # main_pretrain.py:368
-    samples = torch.randn(a.batch, 3, INPUT, INPUT, device=device)
+    samples = torch.randn(a.batch, chans, size, size, device=device)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -172,20 +188,21 @@ def main():
         pass
     if rank == 0:
         ips = a.batch * world * a.steps / elapsed
-        ach = ips / world * GFLOP_PER_IMAGE / 1e3  # TFLOP/s per GPU
-        scale = a.batch == BATCH_PER_GPU and a.loss == "mse"
+        ach = ips / world * gflop / 1e3  # TFLOP/s per GPU
+        scale = a.batch == BATCH_PER_GPU and a.loss == "mse" and a.preset == "base"
         out = {
             "metric": "pretrain images/sec ViT-B/16 224^2 two-scale", "value": round(ips, 2), "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "MAE_ViT_MsLdCeCd ViT-B/16, 224^2 two-scale crops, mask 0.75, AdamW, full optimizer step",
-                       "loss": a.loss, "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [3, INPUT, INPUT], "parallelism": f"dp{world}",
+            "config": {"workload": f"{factory} /{patch}, {size}^2 two-scale crops, mask 0.75, AdamW, full optimizer step" if a.preset != "base" else
+                       "MAE_ViT_MsLdCeCd ViT-B/16, 224^2 two-scale crops, mask 0.75, AdamW, full optimizer step",
+                       "loss": a.loss, "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [chans, size, size], "parallelism": f"dp{world}",
                        "headline_config": bool(scale)},
             "loss": round(final_loss, 5),
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic, "algorithmic_gflop_per_image": GFLOP_PER_IMAGE, "dominant_kernel": kernel},
+                         "traffic": traffic if a.preset == "base" else None, "algorithmic_gflop_per_image": gflop, "dominant_kernel": kernel},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.preset == "base":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
