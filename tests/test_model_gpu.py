@@ -396,3 +396,57 @@ def test_large_and_huge_presets_one_step(name, kw, n):
     FusedAdamW(add_weight_decay(m, 0.05), lr=1e-4, betas=(0.9, 0.95)).step()
     torch.cuda.synchronize()
     assert abs(losses[torch.bfloat16] - losses[torch.float32]) <= 2e-2 * abs(losses[torch.float32]), losses
+
+
+def test_full_size_vitb_224_n128_properties():
+    """BASELINE.json configs[1] at full size (ViT-B/16 MsLdCeCd, 224^2, 128 images, bf16 MFMA path) through properties that need no
+    oracle run: masking indices are permutations in noise order with exactly L - keep masked patches per row; the step is deterministic
+    (two runs on the same draws: bit-identical loss and gradients — every reduction is ordered); the total is the sum of its terms;
+    the backward is exactly linear in the incoming gradient for a power-of-two factor; and the fp32 engine agrees within the bf16
+    tolerance written for the small cases (2e-2)."""
+    import models_mae
+    torch.manual_seed(0)
+    m = models_mae.mae_vit_base_MsLdCeCd(input_size=224, patch_size="16", loss="mse", device="cuda").cuda().train()
+    N, L, keep = 128, 196, 49
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, 3, 224, 224, generator=g).cuda()
+    noise = [torch.rand(N, L, generator=g), torch.rand(N, L, generator=g)]
+    draws = dict(noise=noise, box=(31, 17, 140, 150))
+    names = ("decoder_pred.weight", "encoder.0.attn.qkv.weight", "decoder.3.mlp.fc1.weight", "patch_embed.proj.weight", "cls_token", "predictor.1.weight")
+
+    def run(dtype, scale=1.0):
+        m.compute_dtype = dtype
+        m.zero_grad(set_to_none=True)
+        m._test_draws = dict(draws)
+        loss, pred, mask = m(x)
+        (loss * scale).backward()
+        eng = m._engines[dtype]
+        params = dict(m.named_parameters())
+        return (loss.detach().clone(), mask.clone(), eng.ws.ids_restore.clone(), eng.ws.losses.clone(), {n: params[n].grad.detach().clone() for n in names})
+
+    la, mask, ids, terms, ga = run(torch.bfloat16)
+    lb, _, ids_b, _, gb = run(torch.bfloat16)
+    assert torch.equal(la, lb) and torch.equal(ids, ids_b) and all(torch.equal(ga[n], gb[n]) for n in names)        # deterministic
+    assert torch.isfinite(la) and all(torch.isfinite(v).all() for v in ga.values())
+    # masking (both views): permutation, count, and order — the kept patches are the `keep` smallest noise values of their row
+    assert ids.shape == (2 * N, L) and torch.equal(ids.sort(1).values, torch.arange(L, device="cuda").expand(2 * N, L))
+    full_mask = m._engines[torch.bfloat16].ws.mask
+    assert torch.equal(full_mask.sum(1), torch.full((2 * N,), float(L - keep), device="cuda")) and torch.equal(mask, full_mask[:N])
+    nz = torch.cat(noise).cuda()
+    kept_max = torch.where(full_mask == 0, nz, torch.full_like(nz, -1.0)).max(1).values
+    masked_min = torch.where(full_mask == 1, nz, torch.full_like(nz, 2.0)).min(1).values
+    assert bool((kept_max <= masked_min).all())
+    assert torch.equal(ids, torch.argsort(torch.argsort(nz, dim=1, stable=True), dim=1, stable=True))                 # == the reference's double argsort
+    # the total is the sum of the four terms (reconstruction of both views, cross-decoder, contrastive)
+    t = terms.double().cpu()
+    assert abs(float(t[0]) - float(t[1] + t[2] + t[3] + t[4] + t[5])) < 1e-5 * abs(float(t[0]))
+    # exact linearity of the backward pass for a power-of-two upstream gradient
+    _, _, _, _, g2 = run(torch.bfloat16, scale=2.0)
+    assert all(torch.equal(g2[n], 2.0 * ga[n]) for n in names)
+    # fp32 engine on the same draws
+    lf, _, ids_f, _, gf = run(torch.float32)
+    assert torch.equal(ids_f, ids)
+    assert abs(float(la) - float(lf)) <= 2e-2 * abs(float(lf))
+    for n in names:
+        cos = torch.nn.functional.cosine_similarity(ga[n].flatten().double(), gf[n].flatten().double(), dim=0)
+        assert cos > 0.98, (n, float(cos))
