@@ -44,7 +44,7 @@ _SIGNATURES = {
     "csmae_recon_loss_fwd": [I, I, L, I, I, I, I, P, P, P, L, P, P, P],
     "csmae_recon_loss_bwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P, F, P, P, L, P],
     "csmae_ssim_workspace_floats": [L, I, I, I, I, P],
-    "csmae_ssim_fwd": [I, I, L, I, I, I, I, P, P, P, L, P, P, P, P],
+    "csmae_ssim_fwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P],
     "csmae_ssim_apply": [I, I, F, F, P, P, P],
     "csmae_ssim_bwd": [I, L, I, I, I, I, P, L, P, P, F, P, P, P],
     "csmae_pair_loss_fwd": [I, L, I, P, L, L, L, P, L, L, L, P, P],

@@ -194,8 +194,8 @@ def ssim_workspace_floats(B2, C, S, p, levels):
     return n.value
 
 
-def ssim_fwd(levels, norm_pix, img0, img1, pred, mask, ws, terms, B2, N, C, S, p, st=None):
-    check(load().csmae_ssim_fwd(levels, int(norm_pix), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0), _p(mask), _p(ws), _p(terms),
+def ssim_fwd(levels, norm_pix, img0, img1, pred, mask, ws, terms, B2, N, C, S, p, flags=0, st=None):
+    check(load().csmae_ssim_fwd(levels, flags, int(norm_pix), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0), _p(mask), _p(ws), _p(terms),
                                 st if st is not None else stream()), "csmae_ssim_fwd")
 
 

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void ssim_stat_store_kernel(int views, int whi
 __global__ __launch_bounds__(256) void ssim_prepare_kernel(PatchGeom g, int norm_pix, long long patches, const float* __restrict__ img0,
                                                            const float* __restrict__ img1, const float* __restrict__ pred, long long ldp,
                                                            const float* __restrict__ mask, float* __restrict__ stat, float* __restrict__ X,
-                                                           float* __restrict__ Y) {
+                                                           float* __restrict__ Y, int raw) {
   const int lane = threadIdx.x & 63;
   const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pt >= patches) return;
@@ -412,8 +412,9 @@ __global__ __launch_bounds__(256) void ssim_prepare_kernel(PatchGeom g, int norm
   const float* img = patch_img(g, img0, img1, n2);
   float mu = 0.f, rs = 1.f;
   if (norm_pix) patch_stats(g, img, l, lane, mu, rs);
-  const float plo = stat[v * 8], phi = stat[v * 8 + 1], tlo = stat[v * 8 + 2], thi = stat[v * 8 + 3];
-  const float psc = 1.f / (phi - plo + 1.0e-6f), tsc = 1.f / (thi - tlo + 1.0e-6f);
+  // raw: the operands are compared as they are (util/metrics.py: images already in [0, 1]); otherwise scale_01 of each (loss family)
+  const float plo = raw ? 0.f : stat[v * 8], phi = stat[v * 8 + 1], tlo = raw ? 0.f : stat[v * 8 + 2], thi = stat[v * 8 + 3];
+  const float psc = raw ? 1.f : 1.f / (phi - plo + 1.0e-6f), tsc = raw ? 1.f : 1.f / (thi - tlo + 1.0e-6f);
   const float m = mask ? mask[pt] : 1.f;
   const float* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
   const int gh = l / g.G, gw = l - gh * g.G;
@@ -559,7 +560,8 @@ __global__ __launch_bounds__(256) void ssim_level_fwd_kernel(SsimWin win, int H,
 // ssim: relu(mean) per plane (nonnegative_ssim), averaged.  ms_ssim: prod_l relu(.)^w_l with cs for l < 4 and ssim for l = 4; a
 // clamped factor zeroes the product and (threshold backward selects 0) every gradient of that plane.
 struct SsimStatArgs { int levels, tiles[SSIM_MAX_LEVELS], Ho[SSIM_MAX_LEVELS]; const float* part[SSIM_MAX_LEVELS]; };
-__global__ __launch_bounds__(256) void ssim_stats_kernel(SsimStatArgs a, long long planes, int views, float* __restrict__ coef, float* __restrict__ val) {
+__global__ __launch_bounds__(256) void ssim_stats_kernel(SsimStatArgs a, long long planes, int views, float* __restrict__ coef, float* __restrict__ val,
+                                                         int signed_ssim) {
   const float wts[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
   const long long per_view = planes / views;
   // one wave per plane: the tile partials of a level are summed across the lanes (fixed order: deterministic)
@@ -584,8 +586,8 @@ __global__ __launch_bounds__(256) void ssim_stats_kernel(SsimStatArgs a, long lo
   const float base = -1.f / (float)per_view;
   float v;
   if (a.levels == 1) {
-    v = fmaxf(ms[0], 0.f);
-    cf[0] = ms[0] > 0.f ? base / ((float)a.Ho[0] * a.Ho[0]) : 0.f;
+    v = signed_ssim ? ms[0] : fmaxf(ms[0], 0.f);   // nonnegative_ssim=True in the loss (MAE_ViT_Shared.py:204-206), False in util/metrics.py
+    cf[0] = (signed_ssim || ms[0] > 0.f) ? base / ((float)a.Ho[0] * a.Ho[0]) : 0.f;
   } else {
     float t[SSIM_MAX_LEVELS]; bool pos = true;
     v = 1.f;
@@ -761,8 +763,9 @@ extern "C" int csmae_ssim_workspace_floats(long long B2, int C, int S, int p, in
   *floats = ssim_layout(B2, C, S, p, levels).total;
   return CSMAE_OK;
 }
-extern "C" int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
+extern "C" int csmae_ssim_fwd(int levels, int flags, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
                               const float* pred, long long ldp, const float* mask, float* ws, float* terms, void* stream) {
+  CSMAE_REQUIRE(flags >= 0 && flags <= 3, "csmae_ssim_fwd: bad flags %d", flags);
   CSMAE_REQUIRE(levels == 1 || levels == SSIM_MAX_LEVELS, "csmae_ssim_fwd: levels must be 1 (ssim) or 5 (ms_ssim)");
   CSMAE_REQUIRE(B2 > 0 && N > 0 && B2 % N == 0 && B2 / N <= 2 && S % p == 0 && ws && terms && pred && img0, "csmae_ssim_fwd: bad args");
   CSMAE_REQUIRE(S >= SSIM_WIN, "csmae_ssim_fwd: images smaller than the 11-tap window are not supported (S = %d)", S);
@@ -780,7 +783,7 @@ extern "C" int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int
   hipLaunchKernelGGL(target_minmax_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, norm_pix, patches, img0, img1, mm);
   hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(1024), 0, st, (long long)N * g.L, views, mm, mmout);
   hipLaunchKernelGGL(ssim_stat_store_kernel, dim3(1), dim3(64), 0, st, views, 1, mmout, stat);
-  hipLaunchKernelGGL(ssim_prepare_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, norm_pix, patches, img0, img1, pred, ldp, mask, stat, ws + L.X[0], ws + L.Y[0]);
+  hipLaunchKernelGGL(ssim_prepare_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, st, g, norm_pix, patches, img0, img1, pred, ldp, mask, stat, ws + L.X[0], ws + L.Y[0], flags & 1);
   SsimStatArgs sa; sa.levels = levels;
   for (int l = 0; l < SSIM_MAX_LEVELS; ++l) { sa.tiles[l] = L.tiles[l]; sa.Ho[l] = L.Ho[l]; sa.part[l] = ws + L.part[l]; }
   for (int l = 0; l < levels; ++l) {
@@ -790,7 +793,7 @@ extern "C" int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int
       hipLaunchKernelGGL(ssim_pool_kernel, dim3(cdiv(L.planes * L.H[l + 1] * L.H[l + 1], 256)), dim3(256), 0, st, L.planes, L.H[l], L.pad[l], L.H[l + 1],
                          ws + L.X[l], ws + L.Y[l], ws + L.X[l + 1], ws + L.Y[l + 1]);
   }
-  hipLaunchKernelGGL(ssim_stats_kernel, dim3(cdiv(L.planes, 4)), dim3(256), 0, st, sa, L.planes, views, ws + L.coef, ws + L.val);
+  hipLaunchKernelGGL(ssim_stats_kernel, dim3(cdiv(L.planes, 4)), dim3(256), 0, st, sa, L.planes, views, ws + L.coef, ws + L.val, (flags >> 1) & 1);
   hipLaunchKernelGGL(ssim_terms_kernel, dim3(1), dim3(1024), 0, st, L.planes / views, views, ws + L.val, terms);
   return csmae_check_launch("csmae_ssim_fwd");
 }

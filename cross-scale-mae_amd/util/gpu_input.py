@@ -25,6 +25,11 @@ def sample_transform_params(H: int, W: int, scale=(0.25, 1.0), ratio=(3.0 / 4.0,
     ten (area, log-ratio) proposals with `uniform_`, `randint` for the corner, centre-crop fallback clamped to the ratio range)."""
     hflip = int(torch.rand(1).item() < p_flip)
     vflip = int(torch.rand(1).item() < p_flip)
+    return (H, W) + resized_crop_box(H, W, scale, ratio) + (hflip, vflip)
+
+
+def resized_crop_box(H: int, W: int, scale=(0.25, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)) -> Tuple[int, int, int, int]:
+    """(i, j, h, w) of torchvision 0.15.1 `RandomResizedCrop.get_params`, drawn from the global CPU torch RNG."""
     area = float(H * W)
     lo, hi = math.log(ratio[0]), math.log(ratio[1])
     for _ in range(10):
@@ -35,7 +40,7 @@ def sample_transform_params(H: int, W: int, scale=(0.25, 1.0), ratio=(3.0 / 4.0,
         if 0 < w <= W and 0 < h <= H:
             i = torch.randint(0, H - h + 1, size=(1,)).item()
             j = torch.randint(0, W - w + 1, size=(1,)).item()
-            return H, W, i, j, h, w, hflip, vflip
+            return i, j, h, w
     in_ratio = float(W) / float(H)
     if in_ratio < ratio[0]:
         w = W; h = int(round(w / ratio[0]))
@@ -43,7 +48,7 @@ def sample_transform_params(H: int, W: int, scale=(0.25, 1.0), ratio=(3.0 / 4.0,
         h = H; w = int(round(h * ratio[1]))
     else:
         w, h = W, H
-    return H, W, (H - h) // 2, (W - w) // 2, h, w, hflip, vflip
+    return (H - h) // 2, (W - w) // 2, h, w
 
 
 class GpuAugment:

@@ -111,10 +111,12 @@ int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, long long B2, in
  * partial sums and statistics between the calls (csmae_ssim_workspace_floats floats, caller-allocated, untouched between fwd and bwd).
  * fwd: terms[v] = 1 - score of view v.   apply (after csmae_loss_finalize): losses[1+v] (+)= weight * terms[v], total fixed up
  * (`pure` = no per-patch term, the plain ssim / ms_ssim kinds; otherwise the 0.1-weighted mse_* kinds :249-267).
+ * flags serve util/metrics.py (ssim / ms_ssim of two image batches in [0, 1], :4-10,:41-46): 1 = no min-max scaling, 2 = no relu.
  * bwd: extra[B2*L][P] (fp32) = gout * scale * d terms / d pred, handed to csmae_recon_loss_bwd (kind 5 = no per-patch term). */
 int csmae_ssim_workspace_floats(long long B2, int C, int S, int p, int levels, long long* floats /* host pointer, out */);
-int csmae_ssim_fwd(int levels, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
-                   const float* pred, long long ldp, const float* mask, float* ws, float* terms, void* stream);
+int csmae_ssim_fwd(int levels, int flags /* 1: operands as they are (no scale_01) | 2: signed single-scale score */, int norm_pix,
+                   long long B2, int N, int C, int S, int p, const float* img0, const float* img1, const float* pred, long long ldp,
+                   const float* mask, float* ws, float* terms, void* stream);
 int csmae_ssim_apply(int pure, int views, float weight, float recon_scale, const float* terms, float* losses, void* stream);
 int csmae_ssim_bwd(int levels, long long B2, int N, int C, int S, int p, const float* pred, long long ldp, const float* mask,
                    const float* gout, float scale, float* ws, float* extra, void* stream);

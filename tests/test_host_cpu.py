@@ -184,3 +184,48 @@ def test_checkpoint_key_mapping_to_vit_and_back():
     assert sum(1 for k in vit if k.startswith("blocks.")) == n_enc
     back = from_vit_keys(vit)
     assert back == {k: v for k, v in sd.items() if "encoder" in k or k in ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias")}
+
+
+def test_viz_and_metrics_host_helpers(tmp_path):
+    """util/viz.py / util/metrics.py (eval side): file-name helper, image preparation (PIL path of the reference:
+    RandomResizedCrop box drawn with the torchvision rule, bicubic resize, plot statistics), noise, element-wise metrics, and the
+    explicit errors for what this image cannot do (matplotlib absent; ssim metrics need the GPU)."""
+    from PIL import Image
+    from util import metrics, viz
+    assert viz.title_to_fname("mae_vit_base - epoch 25 - img 1.jpg") == "mae_vit_base_epoch_25_img_1_jpg"
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    path = str(tmp_path / "a.png")
+    Image.fromarray(arr).save(path)
+    img = viz.prepare_image(path, 64)
+    assert img.shape == (64, 64, 3) and img.dtype == np.float64
+    back = img * viz.image_std + viz.image_mean
+    assert 0.0 <= back.min() and back.max() <= 1.0
+    a = viz.prepare_image(path, 64, random_crop=True, crop_seed=7)
+    b = viz.prepare_image(path, 64, random_crop=True, crop_seed=7)
+    c = viz.prepare_image(path, 64, random_crop=True, crop_seed=8)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    torch.manual_seed(7)
+    from util.gpu_input import resized_crop_box
+    i, j, h, w = resized_crop_box(90, 120, scale=(0.25, 1.0))
+    want = np.array(Image.fromarray(arr).resize((64, 64), Image.BICUBIC, box=(j, i, j + w, i + h)).resize((64, 64), resample=None)) / 255.0
+    np.testing.assert_allclose(a, (want - viz.image_mean) / viz.image_std)
+    x = torch.zeros(4, 4, 3)
+    torch.manual_seed(0)
+    assert viz.add_noise(x, "gaussian", 0.1).std() > 0 and set(viz.add_noise(x, "s&p", 0.5).unique().tolist()) <= {0.0, 1.0}
+    with pytest.raises(ValueError):
+        viz.add_noise(x, "pink")
+    u, v = torch.rand(1, 8, 8, 3), torch.rand(1, 8, 8, 3)
+    assert metrics.calc_metric(u, v, "mse") == pytest.approx(((u - v) ** 2).mean().item())
+    assert metrics.calc_metric(u, v, "SSD") == pytest.approx(((u - v) ** 2).sum().item())
+    assert metrics.calc_metric(u, v, "sad") == pytest.approx((u - v).abs().sum().item())
+    assert metrics.calc_metric(u, v, "mae") == pytest.approx((u - v).abs().mean().item())
+    assert set(metrics.METRICS_DICT) == {"mse", "mae", "l1", "l2", "ssim", "ms_ssim"}
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            metrics.calc_metric(u, v, "ssim")
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="matplotlib"):
+            viz.plot_image(torch.zeros(1, 4, 4, 3))

@@ -450,3 +450,53 @@ def test_full_size_vitb_224_n128_properties():
     for n in names:
         cos = torch.nn.functional.cosine_similarity(ga[n].flatten().double(), gf[n].flatten().double(), dim=0)
         assert cos > 0.98, (n, float(cos))
+
+
+def test_metrics_ssim_on_gpu_match_oracle():
+    """util/metrics.py ssim / ms_ssim (data_range 1, signed, operands as they are) through the HIP kernels vs the oracle's restatement of
+    pytorch-msssim; channel-last inputs as util/viz.py hands them over."""
+    import csmae_oracle as O
+    from util import metrics
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 3, 176, 176, generator=g)
+    y = (0.6 * x + 0.4 * torch.rand(2, 3, 176, 176, generator=g)).clamp(0, 1)
+    assert abs(metrics.calc_metric(x.cuda(), y.cuda(), "ssim") - O.ssim(x, y, data_range=1).item()) < 1e-4
+    assert abs(metrics.calc_metric(x.cuda(), y.cuda(), "ms_ssim") - O.ms_ssim(x, y, data_range=1).item()) < 1e-4
+    xl, yl = x[:1].permute(0, 2, 3, 1).contiguous(), y[:1].permute(0, 2, 3, 1).contiguous()   # [1, H, W, C] CPU tensors, as run_one_image returns
+    assert abs(metrics.calc_metric(xl, yl, "ssim") - O.ssim(x[:1], y[:1], data_range=1).item()) < 1e-4
+    neg = metrics.calc_metric(x.cuda(), (1 - x).cuda(), "ssim")   # inverted image: positive means, negative structure term -> signed score < 0
+    assert neg < 0 and abs(neg - O.ssim(x, 1 - x, data_range=1).item()) < 1e-4   # (the loss family would clamp it at 0)
+    with pytest.raises(Exception, match="larger than 160"):
+        metrics.calc_metric(x[:, :, :64, :64].cuda(), y[:, :, :64, :64].cuda(), "ms_ssim")
+
+
+def test_viz_prepare_model_and_run_one_image(tmp_path):
+    """util/viz.py: a checkpoint written by util.misc.save_model comes back as the same model (args -> factory -> weights), and one
+    image through run_one_image obeys the paste identities of util/viz.py:196-206 with the mask the seeded forward returns."""
+    import argparse
+    import models_mae
+    from util import misc, viz
+    torch.manual_seed(3)
+    kw = dict(MICRO, input_size=64, patch_size="16", mask_ratio=0.75)
+    m = models_mae.MAE_ViT_Baseline(**kw, device="cuda").cuda().eval()
+    args = argparse.Namespace(model="MAE_ViT_Baseline", output_dir=str(tmp_path / "run"), device="cuda", **kw)
+    os.makedirs(args.output_dir)
+    misc.save_model(args, 7, m, m, torch.optim.SGD(m.parameters(), lr=0.1), None)
+    m2 = viz.prepare_model("run", chkpt_basedir=str(tmp_path))
+    assert type(m2) is type(m) and next(m2.parameters()).is_cuda
+    for (n, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), n
+    assert viz.prepare_model("run", chkpt_basedir=str(tmp_path), chkpt_name=7) is not None
+    img = np.random.default_rng(1).normal(size=(64, 64, 3))
+    x, xm, y, ym, pasted = viz.run_one_image(img, m2.eval(), mask_seed=1234)
+    assert all(t.shape == (1, 64, 64, 3) and not t.is_cuda for t in (x, xm, y, ym, pasted))
+    np.testing.assert_allclose(x[0].numpy(), img * viz.image_std + viz.image_mean, rtol=1e-9, atol=1e-12)
+    torch.manual_seed(1234)
+    _, pred, mask = m2(torch.as_tensor(img).permute(2, 0, 1)[None].float().cuda(), mask_ratio=0.75)   # mask_seed reproduces this draw
+    _, _, mask2 = m2(torch.as_tensor(img).permute(2, 0, 1)[None].float().cuda(), mask_ratio=0.75, mask_seed=1234)
+    assert torch.equal(mask, mask2) and int(mask.sum()) == 12
+    pix = m2.unpatchify(mask2.unsqueeze(-1).repeat(1, 1, 768), 16, 3).permute(0, 2, 3, 1).cpu()
+    assert torch.allclose(xm, x * (1 - pix)) and torch.allclose(ym, y * pix) and torch.allclose(pasted, xm + ym)
+    assert torch.equal(pasted[pix == 0], x[pix == 0])     # visible patches are the input
+    yy = m2.unpatchify(pred.detach(), 16, 3).permute(0, 2, 3, 1).cpu().double() * torch.as_tensor(viz.image_std) + torch.as_tensor(viz.image_mean)
+    assert torch.allclose(y, yy, rtol=1e-5, atol=1e-6)
