@@ -273,7 +273,7 @@ __global__ __launch_bounds__(1024) void ntx_sim_kernel(int N, int D, const float
 }
 // dL/dc_ij = w * ( [j neg] e_ij / (tau (neg_i+eps))  -  [j == partner] / tau ),  w = gout / 2N ;  dz_i = sum_j (G_ij + G_ji) z_j
 // then through F.normalize: df = (dz - z (z.dz)) * inv_norm ; dpool = df (the 1/keep of the mean is applied by latent_grad_finish)
-__global__ __launch_bounds__(256) void ntx_bwd_kernel(int N, int D, const float* __restrict__ z, const float* __restrict__ inv_norm,
+__global__ __launch_bounds__(1024) void ntx_bwd_kernel(int N, int D, const float* __restrict__ z, const float* __restrict__ inv_norm,
                                                       const float* __restrict__ E, const float* __restrict__ neg, float tau, float eps,
                                                       const float* __restrict__ gout, float* __restrict__ dpool) {
   __shared__ float red[32];
@@ -289,8 +289,14 @@ __global__ __launch_bounds__(256) void ntx_bwd_kernel(int N, int D, const float*
   __syncthreads();
   float dot = 0.f;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float s = 0.f;
-    for (int j = 0; j < B2; ++j) s += coef[j] * z[(long long)j * D + d];
+    float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains: the 2N-long walk is latency-, not bandwidth-bound
+    int j = 0;
+    for (; j + 3 < B2; j += 4) {
+      s += coef[j] * z[(long long)j * D + d]; s1 += coef[j + 1] * z[(long long)(j + 1) * D + d];
+      s2 += coef[j + 2] * z[(long long)(j + 2) * D + d]; s3 += coef[j + 3] * z[(long long)(j + 3) * D + d];
+    }
+    for (; j < B2; ++j) s += coef[j] * z[(long long)j * D + d];
+    s = (s + s1) + (s2 + s3);
     dpool[(long long)i * D + d] = s;
     dot += s * z[(long long)i * D + d];
   }
@@ -309,7 +315,7 @@ extern "C" int csmae_ntxent_fwd(int N, int Te, int keep, int D, const float* lat
 extern "C" int csmae_ntxent_bwd(int N, int D, const float* z, const float* inv_norm, const float* E, const float* neg, float tau, float eps,
                                 const float* gout, float* dpool, void* stream) {
   CSMAE_REQUIRE(N > 0 && D > 0 && 2 * N * 4 <= 64 * 1024, "csmae_ntxent_bwd: bad geometry");
-  hipLaunchKernelGGL(ntx_bwd_kernel, dim3(2 * N), dim3(256), 2 * N * sizeof(float), (hipStream_t)stream, N, D, z, inv_norm, E, neg, tau, eps, gout, dpool);
+  hipLaunchKernelGGL(ntx_bwd_kernel, dim3(2 * N), dim3(D >= 1024 ? 1024 : ((D + 63) / 64) * 64), 2 * N * sizeof(float), (hipStream_t)stream, N, D, z, inv_norm, E, neg, tau, eps, gout, dpool);
   return csmae_check_launch("csmae_ntxent_bwd");
 }
 // dlat[n, t>=1, :] += dpool[n, :] * inv_keep ; then emit the low-precision copy that the encoder backward GEMMs consume

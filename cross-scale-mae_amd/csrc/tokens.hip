@@ -24,29 +24,48 @@ __device__ __forceinline__ void aa_taps(int o, int in_size, int out_size, AxisTa
   for (int k = 0; k < n; ++k) tp.w[k] /= tot;
   tp.lo = lo; tp.n = n;
 }
+// One workgroup = CROP_ROWS output rows of one plane.  The tap tables of the S output columns and of the workgroup's rows are built once
+// in LDS (the first version rebuilt them per thread and kept them in a dynamically indexed private array, i.e. in scratch memory).
+#define CROP_ROWS 8
 __global__ __launch_bounds__(256) void crop_resize_kernel(long long planes, int S, const float* __restrict__ src, float* __restrict__ dst,
                                                           const int* __restrict__ box) {
+  extern __shared__ int crop_lds[];
+  int* xlo = crop_lds; int* xn = xlo + S; float* xw = reinterpret_cast<float*>(xn + S);          // [S], [S], [S][8]
+  int* ylo = reinterpret_cast<int*>(xw + S * 8); int* yn = ylo + CROP_ROWS; float* yw = reinterpret_cast<float*>(yn + CROP_ROWS);  // [R], [R], [R][8]
   const int bi = box[0], bj = box[1], bh = box[2], bw = box[3];
-  const int oy = blockIdx.y;
-  AxisTaps ty; aa_taps(oy, bh, S, ty);
-  for (int ox = threadIdx.x; ox < S; ox += blockDim.x) {
-    AxisTaps tx; aa_taps(ox, bw, S, tx);
-    for (long long pl = blockIdx.x; pl < planes; pl += gridDim.x) {
-      const float* base = src + pl * S * S + (long long)(bi + ty.lo) * S + bj + tx.lo;
-      float acc = 0.f;
-      for (int a = 0; a < ty.n; ++a) {
-        float hsum = 0.f;
-        for (int b = 0; b < tx.n; ++b) hsum += tx.w[b] * base[a * S + b];
-        acc += ty.w[a] * hsum;
-      }
-      dst[pl * S * S + (long long)oy * S + ox] = acc;
+  const int oy0 = blockIdx.x * CROP_ROWS;
+  const long long pl = blockIdx.y;
+  for (int i = threadIdx.x; i < S + CROP_ROWS; i += blockDim.x) {
+    AxisTaps t;
+    const bool isx = i < S;
+    aa_taps(isx ? i : min(oy0 + i - S, S - 1), isx ? bw : bh, S, t);
+    int* lo = isx ? xlo + i : ylo + (i - S); int* n = isx ? xn + i : yn + (i - S);
+    float* w = isx ? xw + i : yw + (i - S) * 8; const int ws = isx ? S : 1;   // x taps tap-major ([8][S]: lanes read consecutive banks)
+    *lo = t.lo; *n = t.n;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k * ws] = k < t.n ? t.w[k] : 0.f;
+  }
+  __syncthreads();
+  const float* plane = src + pl * S * S;
+  for (int i = threadIdx.x; i < CROP_ROWS * S; i += blockDim.x) {
+    const int r = i / S, ox = i - r * S, oy = oy0 + r;
+    if (oy >= S) break;
+    const int ny = yn[r], nx = xn[ox];
+    const float* base = plane + (long long)(bi + ylo[r]) * S + bj + xlo[ox];
+    float acc = 0.f;
+    for (int a = 0; a < ny; ++a) {
+      float hsum = 0.f;
+      for (int b = 0; b < nx; ++b) hsum += xw[b * S + ox] * base[a * S + b];
+      acc += yw[r * 8 + a] * hsum;
     }
+    dst[pl * S * S + (long long)oy * S + ox] = acc;
   }
 }
 extern "C" int csmae_crop_resize(long long planes, int S, const float* src, float* dst, const int* box, void* stream) {
-  CSMAE_REQUIRE(planes > 0 && S > 0 && src && dst && box, "csmae_crop_resize: bad args");
-  dim3 grid((unsigned)fmin((double)planes, 1024.0), S), block(S >= 256 ? 256 : ((S + 63) / 64) * 64);
-  hipLaunchKernelGGL(crop_resize_kernel, grid, block, 0, (hipStream_t)stream, planes, S, src, dst, box);
+  CSMAE_REQUIRE(planes > 0 && planes < 65536 && S > 0 && S <= 2048 && src && dst && box, "csmae_crop_resize: bad args");
+  dim3 grid((S + CROP_ROWS - 1) / CROP_ROWS, (unsigned)planes), block(256);
+  const size_t lds = (size_t)(S + CROP_ROWS) * 10 * sizeof(float);
+  hipLaunchKernelGGL(crop_resize_kernel, grid, block, lds, (hipStream_t)stream, planes, S, src, dst, box);
   return csmae_check_launch("csmae_crop_resize");
 }
 
@@ -131,12 +150,23 @@ extern "C" int csmae_embed_assemble(long long B2, int keep, int D, const float* 
 template <typename T>
 __global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(long long B2, int keep, int D, const float* __restrict__ dx, T* __restrict__ dtok, float* __restrict__ dcls) {
   const int dv = D >> 2;
-  if (blockIdx.y == 0) {  // cls column sums: blocks along x split the columns
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < dv; c += gridDim.x * blockDim.x) {
+  if (blockIdx.y == 0) {  // cls column sums, deterministic: workgroup b owns columns [4b, 4b + 4) (float4 units); its 128 threads are
+    // 4 columns x 32 sample groups, folded through LDS in a fixed order (a serial walk over all 2N samples by D/4 threads of one
+    // workgroup used to be this kernel's whole duration)
+    __shared__ f4_t part[32][4];
+    const int cg = threadIdx.x & 3, sg = threadIdx.x >> 2;
+    for (int c0 = blockIdx.x * 4; c0 < dv; c0 += gridDim.x * 4) {
+      const int c = c0 + cg;
       f4_t s = {0.f, 0.f, 0.f, 0.f};
-      for (long long n = 0; n < B2; ++n) s += *reinterpret_cast<const f4_t*>(dx + n * (keep + 1) * D + c * 4);
-      f4_t o = *reinterpret_cast<f4_t*>(dcls + c * 4) + s;
-      *reinterpret_cast<f4_t*>(dcls + c * 4) = o;
+      if (c < dv) for (long long n = sg; n < B2; n += 32) s += *reinterpret_cast<const f4_t*>(dx + n * (keep + 1) * D + c * 4);
+      __syncthreads();
+      part[sg][cg] = s;
+      __syncthreads();
+      if (sg == 0 && c < dv) {
+        f4_t o = *reinterpret_cast<f4_t*>(dcls + c * 4);
+        for (int k = 0; k < 32; ++k) o += part[k][cg];
+        *reinterpret_cast<f4_t*>(dcls + c * 4) = o;
+      }
     }
     return;
   }
@@ -178,27 +208,41 @@ extern "C" int csmae_unshuffle_fwd(long long B2, int L, int keep, int Dd, const 
 }
 // backward: kept tokens are routed back (unique writers: ids_restore is a permutation), masked positions sum into dmask_token
 template <typename T>
-__global__ __launch_bounds__(128) void unshuffle_bwd_kernel(int L, int keep, int Dd, const float* __restrict__ dxd, const long long* __restrict__ ids_restore,
+__global__ __launch_bounds__(512) void unshuffle_bwd_kernel(int L, int keep, int Dd, const float* __restrict__ dxd, const long long* __restrict__ ids_restore,
                                                             T* __restrict__ dz, float* __restrict__ dmask_token) {
+  // one workgroup per sample; its threads are (column unit, row group): row group g walks rows j = g, g + RG, ... (a single walk over
+  // all L rows by D/4 threads left the kernel latency-bound), the mask-token partials are folded through LDS in a fixed order
+  constexpr int RG = 4;
+  __shared__ f4_t part[RG][128];
   const long long n = blockIdx.x;
-  const int dv = Dd >> 2;
-  for (int c = threadIdx.x; c < dv; c += blockDim.x) {
+  const int dv = Dd >> 2, cl = threadIdx.x & 127, g = threadIdx.x >> 7;
+  for (int c0 = 0; c0 < dv; c0 += 128) {
+    const int c = c0 + cl;
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
-    st4<T>(dz + n * (keep + 1) * Dd + c * 4, *reinterpret_cast<const f4_t*>(dxd + n * (L + 1) * Dd + c * 4));
-    for (int j = 0; j < L; ++j) {
-      long long r = ids_restore[n * L + j];
-      f4_t g = *reinterpret_cast<const f4_t*>(dxd + (n * (L + 1) + 1 + j) * Dd + c * 4);
-      if (r < keep) st4<T>(dz + (n * (keep + 1) + 1 + r) * Dd + c * 4, g); else acc += g;
+    if (c < dv) {
+      if (g == 0) st4<T>(dz + n * (keep + 1) * Dd + c * 4, *reinterpret_cast<const f4_t*>(dxd + n * (L + 1) * Dd + c * 4));
+      for (int j = g; j < L; j += RG) {
+        long long r = ids_restore[n * L + j];
+        f4_t gr = *reinterpret_cast<const f4_t*>(dxd + (n * (L + 1) + 1 + j) * Dd + c * 4);
+        if (r < keep) st4<T>(dz + (n * (keep + 1) + 1 + r) * Dd + c * 4, gr); else acc += gr;
+      }
     }
-    for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dmask_token + c * 4 + k, acc[k]);
+    __syncthreads();
+    part[g][cl] = acc;
+    __syncthreads();
+    if (g == 0 && c < dv) {
+      f4_t s = part[0][cl];
+      for (int k = 1; k < RG; ++k) s += part[k][cl];
+      for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dmask_token + c * 4 + k, s[k]);
+    }
   }
 }
 extern "C" int csmae_unshuffle_bwd(int dtype, long long B2, int L, int keep, int Dd, const float* dxd, const long long* ids_restore, void* dz,
                                    float* dmask_token, void* stream) {
   CSMAE_REQUIRE(B2 > 0 && L > 0 && keep >= 0 && keep <= L && Dd % 4 == 0, "csmae_unshuffle_bwd: bad geometry");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((unshuffle_bwd_kernel<bf16_t>), dim3((unsigned)B2), dim3(128), 0, st, L, keep, Dd, dxd, ids_restore, (bf16_t*)dz, dmask_token);
-  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((unshuffle_bwd_kernel<float>), dim3((unsigned)B2), dim3(128), 0, st, L, keep, Dd, dxd, ids_restore, (float*)dz, dmask_token);
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((unshuffle_bwd_kernel<bf16_t>), dim3((unsigned)B2), dim3(512), 0, st, L, keep, Dd, dxd, ids_restore, (bf16_t*)dz, dmask_token);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((unshuffle_bwd_kernel<float>), dim3((unsigned)B2), dim3(512), 0, st, L, keep, Dd, dxd, ids_restore, (float*)dz, dmask_token);
   else { csmae_set_error("csmae_unshuffle_bwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_unshuffle_bwd");
 }
