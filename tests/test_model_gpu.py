@@ -500,3 +500,77 @@ def test_viz_prepare_model_and_run_one_image(tmp_path):
     assert torch.equal(pasted[pix == 0], x[pix == 0])     # visible patches are the input
     yy = m2.unpatchify(pred.detach(), 16, 3).permute(0, 2, 3, 1).cpu().double() * torch.as_tensor(viz.image_std) + torch.as_tensor(viz.image_mean)
     assert torch.allclose(y, yy, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("variant,S,p,N,mask_ratio", [("MAE_ViT_MsLdCeCd", 96, 16, 3, 0.5), ("MAE_ViT_MsLdLeCd", 112, 14, 2, 0.75),
+                                                      ("MAE_ViT_Baseline", 80, 16, 1, 0.9), ("MAE_ViT_MsLd", 128, 8, 2, 0.6),
+                                                      ("MAE_ViT_MsLdCd", 48, 16, 5, 0.25)])
+def test_odd_geometries_fp32_vs_oracle(variant, S, p, N, mask_ratio):
+    """Geometries away from the benchmark's: 36 / 64 / 25 / 256 / 9 patches, 14- and 8-pixel patches (P = 588, 192), one sample, keep
+    ratios 0.5 / 0.1 / 0.75, odd batch sizes — whole step in fp32 against the oracle on the same weights, noise and crop box."""
+    import models_mae
+    torch.manual_seed(11)
+    cd = dict(predictor_hidden_size=128) if "Cd" in variant else {}
+    m = getattr(models_mae, variant)(**MICRO, input_size=S, patch_size=str(p), mask_ratio=mask_ratio, **cd).cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    L = (S // p) ** 2
+    g = torch.Generator().manual_seed(12)
+    imgs = torch.randn(N, 3, S, S, generator=g)
+    base = variant == "MAE_ViT_Baseline"
+    dr = dict(noise=[torch.rand(N, L, generator=g)] + ([] if base else [torch.rand(N, L, generator=g)]),
+              box=None if base else (S // 9, S // 5, (S * 2) // 3, (S * 5) // 8))
+    m._test_draws = dict(dr)
+    out = m(imgs.cuda(), mask_ratio=mask_ratio)
+    out[0].backward()
+    import csmae_oracle as O
+    osd = O.trainable_copy(sd)
+    cfg = O.make_cfg(input_size=S, input_channels=3, patch_size=p, variant=variant[len("MAE_ViT_"):], predictor_hidden_size=128, **MICRO)
+    bn = None
+    if "predictor.1.running_mean" in osd:
+        bn = dict(running_mean=osd["predictor.1.running_mean"].clone(), running_var=osd["predictor.1.running_var"].clone(),
+                  num_batches_tracked=osd["predictor.1.num_batches_tracked"].clone())
+    oout = O.forward(osd, cfg, imgs, dr["noise"][0], dr["noise"][1] if not base else None, dr["box"], mask_ratio, bn)
+    oout["loss"].backward()
+    assert rel(out[0].detach(), oout["loss"].detach()) < LOSS_RTOL, (float(out[0]), float(oout["loss"]))
+    assert torch.equal(out[2].cpu(), oout["mask"])
+    params = dict(m.named_parameters())
+    for name, q in osd.items():
+        if q.grad is None:
+            assert name not in params or params[name].grad is None or not params[name].requires_grad, name
+            continue
+        got, want = params[name].grad.double().cpu(), q.grad.double()
+        assert (got - want).norm() <= 2e-3 * want.norm() + 1e-9, (name, float((got - want).norm()), float(want.norm()))
+
+
+@pytest.mark.parametrize("variant,S,p,N,mask_ratio", [("MAE_ViT_MsLdCeCd", 96, 16, 3, 0.5), ("MAE_ViT_MsLdLeCd", 112, 14, 2, 0.75),
+                                                      ("MAE_ViT_Baseline", 80, 16, 1, 0.9), ("MAE_ViT_MsLd", 128, 8, 2, 0.6)])
+def test_odd_geometries_bf16_tracks_fp32(variant, S, p, N, mask_ratio):
+    """The same odd geometries through the MFMA path (ragged M / N / K tiles, P = 588, one sample): loss within 2e-2 of the fp32 engine,
+    gradient cosine > 0.98 on every parameter that has one."""
+    import models_mae
+    torch.manual_seed(11)
+    cd = dict(predictor_hidden_size=128) if "Cd" in variant else {}
+    m = getattr(models_mae, variant)(**MICRO, input_size=S, patch_size=str(p), mask_ratio=mask_ratio, **cd).cuda().train()
+    L = (S // p) ** 2
+    g = torch.Generator().manual_seed(12)
+    imgs = torch.randn(N, 3, S, S, generator=g).cuda()
+    base = variant == "MAE_ViT_Baseline"
+    dr = dict(noise=[torch.rand(N, L, generator=g)] + ([] if base else [torch.rand(N, L, generator=g)]),
+              box=None if base else (S // 9, S // 5, (S * 2) // 3, (S * 5) // 8))
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m.compute_dtype = dt
+        m.zero_grad(set_to_none=True)
+        m._test_draws = dict(dr)
+        loss = m(imgs, mask_ratio=mask_ratio)[0]
+        loss.backward()
+        res[dt] = (float(loss.detach()), {n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None})
+    lf, gf = res[torch.float32]
+    lb, gb = res[torch.bfloat16]
+    assert abs(lb - lf) <= 2e-2 * abs(lf), (lb, lf)
+    assert gf.keys() == gb.keys()
+    for n in gf:
+        assert torch.isfinite(gb[n]).all(), n
+        if gf[n].norm() > 1e-7:
+            cos = torch.nn.functional.cosine_similarity(gf[n].flatten().double(), gb[n].flatten().double(), dim=0)
+            assert cos > 0.98, (n, float(cos))
