@@ -345,7 +345,7 @@ def predictor(sd, x: Tensor, bn: Optional[dict] = None, training: bool = True, m
 
 
 # --------------------- models_mae/MAE_ViT_MsLd.py:37-77 + MsLd{Le,Cd,LeCd,CeCd}.py forward bodies
-def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=None):
+def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=None, training=True):
     """Two-view forward with every loss term of the `variant` in cfg.  RNG is external: the caller
     supplies the crop box and both noise tensors (reference draw order: box, rand(N,L), rand(N,L))."""
     variant = cfg["variant"]
@@ -364,7 +364,7 @@ def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=
         out["loss_e"] = loss_fn(cfg.get("loss_e", cfg["loss"]), vo["enc"], vc["enc"])
         total = total + out["loss_e"]
     if variant in ("MsLdCd", "MsLdLeCd", "MsLdCeCd"):  # MAE_ViT_MsLdCeCd.py:56-59 — target NOT detached
-        cross_pred = predictor(sd, vc["dec"][:, 1:, :], bn=bn)
+        cross_pred = predictor(sd, vc["dec"][:, 1:, :], bn=bn, training=training)   # model.eval(): BatchNorm1d normalises with the running statistics
         out["cross_pred"] = cross_pred
         out["loss_cd"] = loss_fn(cfg.get("loss_cd", cfg["loss"]), vo["dec"][:, 1:, :], cross_pred)
         total = total + out["loss_cd"]
@@ -377,10 +377,10 @@ def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=
     return out
 
 
-def forward(sd, cfg, imgs, noise_orig, noise_crop=None, box=None, mask_ratio=0.75, bn=None):
+def forward(sd, cfg, imgs, noise_orig, noise_crop=None, box=None, mask_ratio=0.75, bn=None, training=True):
     if cfg["variant"] == "Baseline":
         return baseline(sd, cfg, imgs, noise_orig, mask_ratio)
-    return cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio, bn)
+    return cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio, bn, training)
 
 
 # -------------------------------------------------- main_pretrain.py:426-427 (timm add_weight_decay)

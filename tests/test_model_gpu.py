@@ -574,3 +574,38 @@ def test_odd_geometries_bf16_tracks_fp32(variant, S, p, N, mask_ratio):
         if gf[n].norm() > 1e-7:
             cos = torch.nn.functional.cosine_similarity(gf[n].flatten().double(), gb[n].flatten().double(), dim=0)
             assert cos > 0.98, (n, float(cos))
+
+
+def test_eval_mode_uses_running_statistics_like_the_oracle():
+    """model.eval(): the predictor's BatchNorm1d normalises with the running statistics the training steps left behind and touches
+    nothing (MLP.py / torch semantics); loss and prediction against the oracle's eval path on the same state."""
+    import csmae_oracle as O
+    d = load("model_micro.npz")
+    m = build("MAE_ViT_MsLdCeCd", micro_sd(d))
+    x = T(d["imgs"]).cuda()
+    for _ in range(2):   # two training forwards move the running statistics and the batch counter
+        m._test_draws = draws(d, "cecd_s0")
+        m(x)
+    assert int(m.predictor[1].num_batches_tracked) == 2
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    before = {k: v.clone() for k, v in sd.items() if k.startswith("predictor.1.")}
+    m.eval()
+    m._test_draws = draws(d, "cecd_s0")
+    with torch.no_grad():
+        loss, pred, mask = m(x)
+    after = m.state_dict()
+    for k, v in before.items():
+        assert torch.equal(after[k].cpu(), v), k
+    osd = O.trainable_copy(sd)
+    cfg = O.make_cfg(input_size=64, input_channels=3, patch_size=16, variant="MsLdCeCd", predictor_hidden_size=128, **MICRO)
+    bn = dict(running_mean=osd["predictor.1.running_mean"].clone(), running_var=osd["predictor.1.running_var"].clone(),
+              num_batches_tracked=osd["predictor.1.num_batches_tracked"].clone())
+    dr = draws(d, "cecd_s0")
+    with torch.no_grad():
+        oout = O.forward(osd, cfg, T(d["imgs"]), dr["noise"][0], dr["noise"][1], dr["box"], 0.75, bn, training=False)
+    assert rel(loss, oout["loss"]) < LOSS_RTOL, (float(loss), float(oout["loss"]))
+    np.testing.assert_allclose(pred.cpu().numpy(), oout["pred"].numpy(), rtol=2e-3, atol=5e-5)
+    # and it differs from what train mode would give on the same inputs (batch statistics)
+    with torch.no_grad():
+        otrain = O.forward(osd, cfg, T(d["imgs"]), dr["noise"][0], dr["noise"][1], dr["box"], 0.75, dict(bn), training=True)
+    assert abs(float(otrain["loss_cd"]) - float(oout["loss_cd"])) > 1e-6
