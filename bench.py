@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (the headline metric is defined at 128)")
     ap.add_argument("--preset", type=str, default="base", choices=list(PRESETS), help="single-GPU slice of another BASELINE.json config (not the headline)")
     ap.add_argument("--loss", type=str, default="mse", help="reconstruction loss (the headline metric is defined with mse; e.g. mse_ssim, ms_ssim for SURVEY §8 f-4)")
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the "
+                    "N > 1 code path with several ranks on one GPU: set CSMAE_BENCH_ONE_GPU=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -114,11 +116,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("CSMAE_BENCH_ONE_GPU"):  # plumbing test only: every rank on device 0 (RCCL refuses that, gloo does not)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(a.backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     import csmae_hip
     csmae_hip.load()

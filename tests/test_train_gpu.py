@@ -176,3 +176,25 @@ def test_data_parallel_two_ranks_on_one_gpu_gloo(tmp_path):
     # ... and they are not simply rank 0's local gradients: the two ranks saw different data
     m = max(float((r0["grads"][n]).abs().max()) for n in r0["grads"])
     assert m > 0
+
+
+def test_bench_two_ranks_plumbing_on_one_gpu():
+    """bench.py's N > 1 path exactly as the driver launches it (torch.distributed.run, one rank per process, barrier + max-over-ranks
+    timing, rank 0 prints ONE JSON line) — with gloo and both ranks on the one GPU of the test box, because RCCL refuses two ranks on a
+    device.  The 8-GPU RCCL run itself is the driver's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSMAE_BENCH_ONE_GPU="1")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-kernel-timing"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0 and np.isfinite(d["loss"]) and "cpu_baseline" not in d
+    assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-2 * d["value"]
