@@ -5,7 +5,7 @@
 import argparse, json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "cross-scale-mae_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "cross-scale-mae_amd"))
 from util.gpu_input import FMOW_RGB_MEAN, FMOW_RGB_STD, GpuAugment, pack_uint8, sample_transform_params
 
 ap = argparse.ArgumentParser()
@@ -41,16 +41,9 @@ for _ in range(a.iters):
     ops.augment_u8(src, meta, aug.mean, aug.inv_std, dst)
 e1.record(); torch.cuda.synchronize()
 t_k = e0.elapsed_time(e1) / a.iters * 1e-3
-# (3) host baseline on a bounded sample
-import csmae_oracle as O
-k = min(a.n, 16)
-t0 = time.perf_counter()
-for n in range(k):
-    O.train_transform(imgs[n], params[n], FMOW_RGB_MEAN, FMOW_RGB_STD, a.size)
-t_cpu = (time.perf_counter() - t0) / k
 read_b = sum(p[4] * p[5] * 3 for p in params); write_b = a.n * 3 * a.size * a.size * 4
 print(json.dumps({"metric": "input step images/s (decoded uint8 -> normalised fp32 crops)", "n": a.n, "src": a.src, "size": a.size,
                   "kernel_images_per_s": round(a.n / t_k, 1), "kernel_us": round(t_k * 1e6, 1),
                   "kernel_hbm_gbps_algorithmic": round((read_b + write_b) / t_k / 1e9, 1),
                   "pinned_copy_h2d_kernel_images_per_s": round(a.n / t_all, 1), "h2d_mb_per_batch": round(packed.data.numel() / 2 ** 20, 1),
-                  "cpu_port_images_per_s_1thread_equiv": round(1.0 / t_cpu, 1), "cpu_threads": torch.get_num_threads()}))
+                  }))
