@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the GPU input step on synthetic decoded images, next to the same transform chain on the host
-(the oracle's torch restatement of util/datasets.py:120-136).  Prints one JSON line.
+"""Throughput of the GPU input step on synthetic decoded images: the kernel alone and the whole main-process path
+(pinned copy + H2D + kernel).  Prints one JSON line.
     python tools/input_bench.py [--n 128] [--src 512] [--size 224]"""
 import argparse, json, os, sys, time
 import torch
