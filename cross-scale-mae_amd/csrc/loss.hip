@@ -425,14 +425,16 @@ __global__ __launch_bounds__(256) void ssim_prepare_kernel(PatchGeom g, int norm
   const float* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
   const int gh = l / g.G, gw = l - gh * g.G;
   int nlo = 0, nhi = 0;
-  for (int e = lane; e < g.P; e += 64) {
-    const int c = e % g.C, r = e / g.C, ph = r / g.p, pw = r - ph * g.p;
-    const long long o = ((n2 * g.C + c) * g.S + gh * g.p + ph) * g.S + gw * g.p + pw;
-    const float pv = pr[e];
-    nlo += pv == plo; nhi += pv == phi;
-    X[o] = (pv - plo) * psc * m;
-    Y[o] = ((patch_elem(g, img, l, e) - mu) * rs - tlo) * tsc * m;
-  }
+  const int pp = g.p * g.p;
+  for (int c = 0; c < g.C; ++c)            // channel-major walk: a wave's stores are whole p-pixel row segments of ONE plane (the element
+    for (int r = lane; r < pp; r += 64) {  // order of a patch row interleaves the channels; its 12-byte-strided reads hit the cache)
+      const int ph = r / g.p, pw = r - ph * g.p, e = r * g.C + c;
+      const long long o = ((n2 * g.C + c) * g.S + gh * g.p + ph) * g.S + gw * g.p + pw;
+      const float pv = pr[e];
+      nlo += pv == plo; nhi += pv == phi;
+      X[o] = (pv - plo) * psc * m;
+      Y[o] = ((img[((long long)c * g.S + gh * g.p + ph) * g.S + gw * g.p + pw] - mu) * rs - tlo) * tsc * m;
+    }
   if (nlo) atomicAdd(reinterpret_cast<int*>(stat) + v * 8 + 6, nlo);
   if (nhi) atomicAdd(reinterpret_cast<int*>(stat) + v * 8 + 7, nhi);
 }
