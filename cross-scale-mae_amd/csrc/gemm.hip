@@ -783,7 +783,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
   // read while the current row's MFMAs issue (two 4-register buffers), the B fragments are double-buffered per half (2 x 32), the
   // staging registers (64) are written to the other LDS image during the first half and refilled from global memory after the
   // step's barrier.  `sched_barrier` pins this order; the compiler only inserts the waits.
-  s8_t fa[2], fb[2][FN];
+  constexpr int AD = 3;       // A fragments are fetched AD rows ahead into a ring of four buffers (16 rows per step: the ring phase is static)
+  s8_t fa[4], fb[2][FN];
   gload(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -792,7 +793,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
   gload(1);
 #pragma unroll
   for (int j = 0; j < FN; ++j) fb[0][j] = read_b(0, 0, j);
-  fa[0] = read_a(0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < AD; ++r) fa[r] = read_a(0, 0, r);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     char* sta = smem + (buf ^ 1) * 2 * IMG + soff;
@@ -800,27 +802,51 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
     // fragments are never used — no branches in the loop body)
     static_for<2 * FM>([&](auto rc) {
       constexpr int r = decltype(rc)::value, h = r / FM, i = r % FM;
-      // the next row's A fragment (the next step's first one comes from the other image, after the barrier below)
-      if (r + 1 < 2 * FM) fa[(r + 1) & 1] = read_a(buf, (r + 1) / FM, (r + 1) % FM);
-      else fa[0] = read_a(buf ^ 1, 0, 0);
+      // One row = eight MFMAs.  With a single wave per SIMD nothing else hides the row's memory instructions: they are interleaved
+      // one by one BETWEEN the MFMAs (the matrix pipe takes an MFMA every 16 cycles, the wave can issue something else in the gap).
+#define W4_MFMA(j) do { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(j) / 4][i][(j) % 4]) : "v"(fb[h][j]), "v"(fa[r & 3])); \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+      W4_MFMA(0);
+      // the A fragment of row r + AD (the next step's first rows come from the other image: r + AD >= 16 only after the barrier of row 9)
+      if (r + AD < 2 * FM) fa[(r + AD) & 3] = read_a(buf, (r + AD) / FM, (r + AD) % FM);
+      else fa[(r + AD) & 3] = read_a(buf ^ 1, 0, r + AD - 2 * FM);
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA(1);
       // B fragments of the other half: this step's second half during the first, the next step's first half after the barrier
       if (h == 0) fb[1][i] = read_b(buf, 1, i);
       else if (r >= FM + 2) {
         constexpr int q = r - (FM + 2);                      // rows 10..15 fetch fragments 0..7 as 2, 2, 1, 1, 1, 1
-        if (q == 0) { fb[0][0] = read_b(buf ^ 1, 0, 0); fb[0][1] = read_b(buf ^ 1, 0, 1); }
-        else if (q == 1) { fb[0][2] = read_b(buf ^ 1, 0, 2); fb[0][3] = read_b(buf ^ 1, 0, 3); }
+        if (q == 0) fb[0][0] = read_b(buf ^ 1, 0, 0);
+        else if (q == 1) fb[0][2] = read_b(buf ^ 1, 0, 2);
         else fb[0][q + 2] = read_b(buf ^ 1, 0, q + 2);
       }
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j / 4][i][j % 4]) : "v"(fb[h][j]), "v"(fa[r & 1]));   // accumulate in place, in the AGPRs
-      if (h == 0) {
-        // stage chunk i of the next image (its two loads were issued one step ago: 14 younger loads are in flight), then refill the
-        // two registers for step kt + 2
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA(2);
+      if (h == 1 && r == FM + 2) fb[0][1] = read_b(buf ^ 1, 0, 1);
+      if (h == 1 && r == FM + 3) fb[0][3] = read_b(buf ^ 1, 0, 3);
+      if (h == 0) {   // chunk i of the next image: its two loads were issued one step ago (14 younger loads are in flight)
         asm volatile("s_waitcnt vmcnt(14)" : "+v"(sa[i]), "+v"(sb[i]) :: "memory");
-        stage1(sta, kt + 1, i);
-        gload1(kt + 2, i);
+        *reinterpret_cast<u4_t*>(sta + i * 32 * 128) = sa[i];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA(3);
+      if (h == 0) *reinterpret_cast<u4_t*>(sta + IMG + i * 32 * 128) = sb[i];
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA(4);
+      if (h == 0) {   // refill the two staging registers for step kt + 2
+        const unsigned ko = (unsigned)(min(kt + 2, nk - 1) * 128 + c * 16);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sa[i]) : "v"(ao[i] + ko), "s"(p.A) : "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA(5);
+      if (h == 0) {
+        const unsigned ko = (unsigned)(min(kt + 2, nk - 1) * 128 + c * 16);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sb[i]) : "v"(bo[i] + ko), "s"(p.B) : "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA(6);
+      W4_MFMA(7);
+#undef W4_MFMA
       if (r == FM + 1) __syncthreads();                      // next image complete and visible; nobody still reads the image before this one
       __builtin_amdgcn_sched_barrier(0);
     });
