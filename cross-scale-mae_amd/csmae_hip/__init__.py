@@ -54,7 +54,9 @@ _SIGNATURES = {
     "csmae_latent_grad_finish": [I, L, I, I, P, P, F, P, P],
     "csmae_loss_finalize": [L, I, P, P, F, P, F, P, F, P, I, P, P],
     "csmae_augment_u8": [L, I, I, I, I, P, P, P, P, P, P],
-    "csmae_adamw": [L, P, P, P, P, P, P, P, F, F, F, F, F, F, P, P],
+    "csmae_adamw": [L, P, P, P, P, P, P, P, F, F, F, F, F, F, P, P, P],
+    "csmae_gate_accumulate": [P, P, I, P],
+    "csmae_clip_grad_norm": [L, P, F, P, P, P],
     "csmae_cast_f32_to_bf16": [L, P, P, P],
     "csmae_colsum": [I, L, I, P, L, P, P],
 }
@@ -81,7 +83,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = sig
         fn.restype = c_int
-    if lib.csmae_abi_version() != 1:
+    if lib.csmae_abi_version() != 2:
         raise CsmaeError("libcsmae_hip ABI version mismatch")
     _lib = lib
     return lib

@@ -47,8 +47,12 @@ class FlatParams:
             off += _round_up(n, 8)
         self.total = off
         self.p = torch.zeros(off, device=device, dtype=torch.float32)
-        self.g = torch.zeros(off, device=device, dtype=torch.float32)
+        # gradient buffer + one tail slot: the update gate (the step's loss; see csmae_adamw).  It sits inside the last all-reduce
+        # range, so with N > 1 every rank gates its optimizer step on the same rank-averaged value.
+        self.g = torch.zeros(off + 8, device=device, dtype=torch.float32)
+        self.gate = self.g[off:off + 1]
         self.w_lp: Optional[torch.Tensor] = None  # bf16 mirror (allocated on demand)
+        self.lp_stamp = None   # sum of the parameters' version counters when the mirror was last made consistent (None: stale)
         self.params = dict(params)
         with torch.no_grad():
             for name, p in params:
@@ -80,6 +84,15 @@ class FlatParams:
 
     def slot_of(self, p):
         return self.slots[self._by_id[id(p)]]
+
+    def version_stamp(self) -> int:
+        """Moves whenever somebody writes a Parameter in place through torch (load_state_dict, torch.optim, `p.mul_()` ...).  The
+        flat buffer's own counter does not: after `p.data = view` every Parameter keeps a version counter of its own."""
+        return sum(p._version for p in self.params.values())
+
+    def mark_changed(self):
+        """Writes torch cannot see (`p.data.mul_()`, raw pointers) must call this so that the bf16 mirror is recast."""
+        self.lp_stamp = None
 
     def still_homed(self) -> bool:
         first = self.params[self.names[0]]
@@ -204,9 +217,9 @@ class Engine:
                 self.w_pe_pad = torch.zeros(cfg["D"], self.Pp, device=self.device, dtype=torch.bfloat16)
                 self.w_pred_pad = torch.zeros(self.Pp, cfg["Dd"], device=self.device, dtype=torch.bfloat16)
         self.ws: Optional[Workspace] = None
-        self.lp_fresh = False  # (kept for callers that still set it; the mirror is tracked by version, see _refresh_lp)
-        self._lp_ver = None
         self._saved = None
+        self.gen = 0            # forward() counter: an autograd node may only run the backward of the forward it belongs to
+        self._gen_done = -1
         self.side, self.main, self.aux = None, None, None
         self._fwd_streams = []
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
@@ -221,14 +234,16 @@ class Engine:
 
     def _refresh_lp(self):
         """Bring the bf16 weight mirror up to date.  FusedAdamW writes the mirror in the same kernel that steps the fp32 master (through
-        raw pointers: the tensor version does not move), so a full recast (0.7 GB of HBM traffic for ViT-B) is only needed when somebody
-        else has written the parameters in place — torch.optim, load_state_dict, manual edits — which bumps `flat.p._version`."""
+        raw pointers: no version counter moves), so a full recast (0.7 GB of HBM traffic for ViT-B) is only needed when somebody else
+        has written the parameters in place — torch.optim, load_state_dict, manual edits.  Those bump the *Parameters'* version
+        counters (not the flat buffer's: `p.data = view` gave every Parameter its own), so the stamp is their sum; it lives on the
+        FlatParams because every engine of a model shares the one mirror."""
         if self.T != BF16:
             return
-        ver = self.flat.p._version
-        if ver != self._lp_ver:
+        stamp = self.flat.version_stamp()
+        if stamp != self.flat.lp_stamp:
             ops.cast_bf16(self.flat.p, self.flat.w_lp)
-            self._lp_ver = ver
+            self.flat.lp_stamp = stamp
         if self.Pp != self.cfg["P"]:
             P = self.cfg["P"]
             self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
@@ -478,7 +493,8 @@ class Engine:
         ops.loss_finalize(N * L, self.views, ws.rowloss, ws.mask, rscale, ws.losses, st=st, **kw)
         if ssim is not None:
             ops.ssim_apply(kind == "none", self.views, ssim[2], rscale, ws.ssim_terms, ws.losses, st=st)
-        self._saved = dict(img0=img0, img1=img1, N=N, keep=keep, mm=mm, rscale=rscale)
+        self.gen += 1
+        self._saved = dict(img0=img0, img1=img1, N=N, keep=keep, mm=mm, rscale=rscale, gen=self.gen)
         return ws
 
     # ------------------------------------------------------------------ stand-alone halves (inference, one view)
@@ -540,10 +556,21 @@ class Engine:
         return 1.0 / (rows * D) if kind in ("mse", "mae") else 1.0 / rows
 
     # ------------------------------------------------------------------ backward
-    def backward(self, gout: torch.Tensor, accumulate: bool):
+    def backward(self, gout: torch.Tensor, accumulate: bool, gen: Optional[int] = None):
+        """Reverse pass of the LAST forward (the activations live in the engine's one workspace).  `gen` = the forward this call
+        belongs to (the autograd node passes it): a forward that has been overwritten by a later one, or whose backward already ran,
+        raises instead of silently differentiating somebody else's activations."""
         c, ws, sv = self.cfg, self.ws, self._saved
         if sv is None:
             raise RuntimeError("backward() called without a preceding forward()")
+        if gen is not None and gen != sv["gen"]:
+            raise RuntimeError("csmae_hip: backward of a forward whose activations are gone — the model ran another forward (training, eval "
+                               "or viz) in between; the engine keeps ONE activation workspace, so call loss.backward() before the next "
+                               "model(...) (accumulate gradients across backward calls, not across forwards)")
+        if sv["gen"] == self._gen_done:
+            raise RuntimeError("csmae_hip: backward called twice for the same forward (retain_graph is not supported: the reverse pass "
+                               "consumes the workspace)")
+        self._gen_done = sv["gen"]
         P, G = self.flat.P, self.flat.G
         self.st = st = ops.stream()
         N, keep = sv["N"], sv["keep"]
@@ -555,6 +582,7 @@ class Engine:
         self._side_reads.clear()
         if not accumulate:
             self.flat.g.zero_()
+        ops.gate_accumulate(ws.losses, self.flat.gate, accumulate, st=st)
         ws.gout.copy_(gout.reshape(1).to(torch.float32))
         kind, npx = c["loss"], c["norm_pix"]
         # reconstruction head

@@ -241,11 +241,22 @@ def loss_finalize(per_view, views, rowloss, mask, recon_scale, losses, cd_partia
                                      _p(ce_rowloss), ce_rows, _p(losses), st if st is not None else stream()), "csmae_loss_finalize")
 
 
-def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps, step, p_lp=None, st=None):
-    """One fused AdamW step over the tiles; `step` (1-based) sets the bias corrections 1 - beta^step."""
+def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps, step, p_lp=None, gate=None, st=None):
+    """One fused AdamW step over the tiles; `step` (1-based) sets the bias corrections 1 - beta^step; a non-finite `gate` (device
+    scalar) turns the launch into a no-op."""
     check(load().csmae_adamw(tile_off.numel(), _p(tile_off), _p(tile_cnt), _p(tile_wd), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1),
-                             float(beta2), float(eps), 1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(p_lp), st if st is not None else stream()),
-          "csmae_adamw")
+                             float(beta2), float(eps), 1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(p_lp), _p(gate),
+                             st if st is not None else stream()), "csmae_adamw")
+
+
+def gate_accumulate(loss, slot, accumulate, st=None):
+    check(load().csmae_gate_accumulate(_p(loss), _p(slot), int(accumulate), st if st is not None else stream()), "csmae_gate_accumulate")
+
+
+def clip_grad_norm(g, max_norm, scratch, out, st=None):
+    """out[0] = ||g||_2, out[1] = min(1, max_norm / (norm + 1e-6)); g *= out[1] in place (max_norm <= 0: norm only)."""
+    check(load().csmae_clip_grad_norm(g.numel(), _p(g), float(max_norm), _p(scratch), _p(out), st if st is not None else stream()),
+          "csmae_clip_grad_norm")
 
 
 def augment_u8(src, meta, mean, inv_std, dst, st=None):

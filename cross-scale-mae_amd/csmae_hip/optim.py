@@ -39,6 +39,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise RuntimeError("FusedAdamW: parameters are not homed in a csmae_hip flat buffer yet — run one forward pass of the model on the "
                                "GPU before the first optimizer step")
         if flat is not self._flat:
+            self._sync_steps()  # (the step counts live in the plans that are about to be dropped)
             self._flat, self._plans = flat, {}
             self._m = torch.zeros_like(flat.p)
             self._v = torch.zeros_like(flat.p)
@@ -59,6 +60,8 @@ class FusedAdamW(torch.optim.Optimizer):
         key = (gi, active)
         if key not in self._plans:
             self._sync_steps()
+            for old in [k for k in self._plans if k[0] == gi]:  # the group's active set changed: its old plan (and counter) is superseded
+                del self._plans[old]
             offs, cnts, params = [], [], []
             for p in group["params"]:
                 if p.grad is None:
@@ -72,13 +75,26 @@ class FusedAdamW(torch.optim.Optimizer):
             wd = float(group["weight_decay"])
             self._plans[key] = dict(off=torch.tensor(offs, dtype=torch.long, device=dev), cnt=torch.tensor(cnts, dtype=torch.int32, device=dev),
                                     wd=torch.full((len(offs),), wd, device=dev), wd_host=wd, params=params,
-                                    step=int(self.state[params[0]]["step"]) if params else 0)
+                                    step=self._common_step(params))
         return self._plans[key]
+
+    def _common_step(self, params):
+        """torch.optim.AdamW counts steps per parameter; one launch per group needs one bias correction.  Parameters of a group that
+        have been stepped a different number of times (possible only when the set of parameters with gradients changed mid-run)
+        cannot share a launch: say so instead of silently using the first one's count."""
+        steps = {int(self.state[p]["step"]) for p in params}
+        if len(steps) > 1:
+            raise RuntimeError(f"FusedAdamW: parameters of one group have different step counts {sorted(steps)} (the set of parameters "
+                               "with gradients changed during training); use torch.optim.AdamW for such a schedule")
+        return steps.pop() if steps else 0
 
     @torch.no_grad()
     def step(self, closure=None):
         """No host<->device synchronisation and no staging copies in here: the hyper-parameters are kernel arguments, the step counter
-        and the weight decay live on the host, so the CPU keeps enqueueing the next step while the GPU is still in this one's backward."""
+        and the weight decay live on the host, so the CPU keeps enqueueing the next step while the GPU is still in this one's backward.
+        The launches are gated on the device: when the loss behind these gradients was not finite (the engine leaves it in
+        `flat.gate`, all-reduced with the gradients) the kernels return without touching weights, moments or the bf16 mirror — the
+        reference raises before `backward` (engine_pretrain.py:56-58), this loop only notices at its next loss drain."""
         loss = closure() if closure is not None else None
         flat = self._bind()
         g0 = flat.g.data_ptr()
@@ -98,7 +114,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 plan["wd"].fill_(wd)
                 plan["wd_host"] = wd
             b1, b2 = group["betas"]
-            ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp)
+            ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp,
+                      gate=flat.gate)
             self._dirty_steps = True
         return loss
 

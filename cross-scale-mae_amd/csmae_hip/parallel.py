@@ -76,7 +76,8 @@ class GradSync:
             dist.broadcast(t, src=src, group=self.group)
 
 
-def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket: int = 4, taper: bool = False) -> List[Tuple[str, int, int]]:
+def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket: int = 4, taper: bool = False,
+                  tail_extra: int = 0) -> List[Tuple[str, int, int]]:
     """Contiguous flat ranges in gradient-READY order (reverse registration order): tail (decoder + heads), encoder layers in
     groups from the last to the first, then the stem (tokens, patch embed, decoder_embed).  With `taper` the groups shrink
     towards the end of the backward pass (…, 4, 2, 1, 1): whatever is reduced after the last backward kernel is exposed time, so
@@ -90,7 +91,7 @@ def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket:
     out = []
     dec0 = start("decoder.0.")
     enc0 = start("encoder.0.")
-    out.append(("tail", dec0, total))
+    out.append(("tail", dec0, total + tail_extra))  # (+ the update-gate slot behind the last parameter, FlatParams.gate)
     hi = dec0
     i = n_encoder
     while i > 0:
@@ -103,6 +104,34 @@ def bucket_ranges(slots: dict, names: List[str], n_encoder: int, enc_per_bucket:
         hi, i = lo, j
     out.append(("stem", 0, enc0))
     return out
+
+
+class FlatBuffers:
+    """The module's buffers (BatchNorm running statistics and step counter of the predictor: 2 x L floats + one int64) re-homed
+    into ONE byte buffer, so that DDP's per-forward `broadcast_buffers` is a single small broadcast instead of one per tensor
+    (three latency-bound RCCL launches on the critical path in front of every forward)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.items = [(n, b) for n, b in module.named_buffers() if b is not None]
+        self.raw = None
+        self.views = []
+        if not self.items:
+            return
+        dev = self.items[0][1].device
+        offs, off = [], 0
+        for _, b in self.items:
+            offs.append(off)
+            off += (b.numel() * b.element_size() + 15) // 16 * 16
+        self.raw = torch.zeros(off, dtype=torch.uint8, device=dev)
+        with torch.no_grad():
+            for (_, b), o in zip(self.items, offs):
+                v = self.raw[o:o + b.numel() * b.element_size()].view(b.dtype).view(b.shape)
+                v.copy_(b)
+                b.data = v   # in-place updates by the kernels (running statistics) and by load_state_dict now land in the flat buffer
+                self.views.append(v)
+
+    def still_homed(self) -> bool:
+        return all(b.data_ptr() == v.data_ptr() and b.device == v.device for (_, b), v in zip(self.items, self.views))
 
 
 class DataParallel(torch.nn.Module):
@@ -121,10 +150,19 @@ class DataParallel(torch.nn.Module):
         if self._sync is None or self._sync.g is not flat.g:
             self._sync = GradSync(flat.g, comm_dtype=self.comm_dtype)
             # rank-0 parameters and buffers win (DDP constructor semantics, main_pretrain.py:418-420)
-            self._sync.broadcast([flat.p] + [b for b in self.module.buffers()])
+            self._sync.broadcast([flat.p])
+            self._broadcast_buffers()
             n_enc = len(self.module.encoder)
-            self._ranges = {name: (lo, hi) for name, lo, hi in bucket_ranges(flat.slots, flat.names, n_enc, taper=True)}
+            self._ranges = {name: (lo, hi) for name, lo, hi in bucket_ranges(flat.slots, flat.names, n_enc, taper=True,
+                                                                               tail_extra=flat.g.numel() - flat.total)}
         return self._sync
+
+    def _broadcast_buffers(self):
+        fb = self.__dict__.get("_fbuf")
+        if fb is None or not fb.still_homed():   # first use, or the module was moved (`.to()` re-allocates every buffer)
+            fb = self.__dict__["_fbuf"] = FlatBuffers(self.module)
+        if fb.raw is not None:
+            self._sync.broadcast([fb.raw])
 
     # called by Engine.backward
     def grads_ready(self, flat, name):
@@ -148,7 +186,7 @@ class DataParallel(torch.nn.Module):
                 self.module._engine(args[0])  # homes the parameters in the flat buffers so they can be broadcast before first use
             self._ensure(self.module._flat)
             if self.module.training:  # DDP broadcast_buffers=True: BatchNorm statistics follow rank 0
-                self._sync.broadcast(list(self.module.buffers()))
+                self._broadcast_buffers()
         return self.module(*args, **kwargs)
 
     class _NoSync:

@@ -11,7 +11,11 @@
 __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict__ tile_off, const int* __restrict__ tile_cnt,
                                                     const float* __restrict__ tile_wd, float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2, float eps,
-                                                    float bc1, float bc2, bf16_t* __restrict__ p_lp) {
+                                                    float bc1, float bc2, bf16_t* __restrict__ p_lp, const float* __restrict__ gate) {
+  // update gate (device scalar, nullable): the step's loss, summed over micro-steps and averaged over ranks with the gradients (it
+  // rides in the tail slot of the flat gradient buffer).  A non-finite value means non-finite gradients on every rank: the update
+  // is skipped as a whole — weights, moments and the bf16 mirror stay as they are — and the host raises at its next loss drain.
+  if (gate != nullptr && !isfinite(gate[0])) return;
   const long long off = tile_off[blockIdx.x];
   const int cnt = tile_cnt[blockIdx.x];
   const float wd = tile_wd[blockIdx.x];
@@ -43,12 +47,74 @@ __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict_
 }
 extern "C" int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
                            float* m, float* v, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
-                           void* p_lp, void* stream) {
+                           void* p_lp, const float* gate, void* stream) {
   CSMAE_REQUIRE(ntiles > 0 && tile_off && tile_cnt && tile_wd && p && g && m && v, "csmae_adamw: null argument");
   CSMAE_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, "csmae_adamw: bias corrections must be positive (step >= 1)");
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps,
-                     bias_correction1, bias_correction2, (bf16_t*)p_lp);
+                     bias_correction1, bias_correction2, (bf16_t*)p_lp, gate);
   return csmae_check_launch("csmae_adamw");
+}
+
+// ---- global gradient norm + clip over the flat gradient buffer (util/misc.py:299-335: `torch.nn.utils.clip_grad_norm_(parameters, clip_grad)`
+// or `get_grad_norm_`).  All gradients are one contiguous fp32 buffer (slots of frozen / unused parameters hold zeros), so the
+// 2-norm is one streaming pass in a fixed order (deterministic two-stage sum, fp32 like torch's foreach norm) and the clip is one
+// in-place scale by min(1, max_norm / (norm + 1e-6)) read from device memory: no host synchronisation anywhere.
+#define NORM_BLOCKS 1024
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(long long n, const float* __restrict__ g, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const long long n4 = n >> 2;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f4_t x = *reinterpret_cast<const f4_t*>(g + i * 4);
+    s += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float x = g[n4 * 4 + threadIdx.x]; s += x * x; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void norm_finish_kernel(const float* __restrict__ partial, float max_norm, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < NORM_BLOCKS; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    out[0] = nrm;
+    out[1] = max_norm > 0.f ? fminf(max_norm / (nrm + 1.0e-6f), 1.0f) : 1.0f;   // torch: clamp(max_norm / (total_norm + 1e-6), max=1.0)
+  }
+}
+__global__ __launch_bounds__(256) void grad_scale_kernel(long long n, float* __restrict__ g, const float* __restrict__ coef) {
+  const float c = coef[1];
+  if (c == 1.0f) return;   // (x * 1.0f is x: nothing to write; a NaN coefficient — non-finite norm — is applied, as torch does)
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f4_t x = *reinterpret_cast<f4_t*>(g + i * 4);
+    x *= c;
+    *reinterpret_cast<f4_t*>(g + i * 4) = x;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) g[n4 * 4 + threadIdx.x] *= c;
+}
+extern "C" int csmae_clip_grad_norm(long long n, float* g, float max_norm, float* scratch, float* out, void* stream) {
+  CSMAE_REQUIRE(n > 0 && g && scratch && out && (((uintptr_t)g & 15) == 0), "csmae_clip_grad_norm: bad arguments (g must be 16-byte aligned, scratch >= 1024 floats)");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, n, g, scratch);
+  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, st, scratch, max_norm, out);
+  if (max_norm > 0.f) hipLaunchKernelGGL(grad_scale_kernel, dim3(2048), dim3(256), 0, st, n, g, out);
+  return csmae_check_launch("csmae_clip_grad_norm");
+}
+
+// update gate bookkeeping: slot (+)= loss (accumulate = 0: slot = loss).  The slot is the tail element of the flat gradient buffer.
+__global__ void gate_kernel(const float* __restrict__ loss, float* __restrict__ slot, int accumulate) {
+  slot[0] = accumulate ? slot[0] + loss[0] : loss[0];
+}
+extern "C" int csmae_gate_accumulate(const float* loss, float* slot, int accumulate, void* stream) {
+  CSMAE_REQUIRE(loss && slot, "csmae_gate_accumulate: null argument");
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss, slot, accumulate);
+  return csmae_check_launch("csmae_gate_accumulate");
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(long long n, const float* __restrict__ src, bf16_t* __restrict__ dst) {

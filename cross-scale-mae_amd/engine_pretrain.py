@@ -4,7 +4,9 @@
 * the reference synchronises host and device four times per iteration (loss.item(), GradScaler found-inf, cuda.synchronize(),
   all_reduce_mean().item()); here the per-iteration losses stay on the device and are drained every `print_freq` iterations,
   so kernels of step k+1 are enqueued while step k still runs.  Meter contents and the non-finite-loss ValueError are the same,
-  the error is just raised at the next drain instead of the same iteration;
+  the error is just raised at the next drain instead of the same iteration — on every rank at the same drain — and the fused
+  optimizer skips, on the device, every update whose loss was not finite (csmae_adamw's gate), so weights and AdamW moments
+  are still the last good ones when the error surfaces;
 * `torch.cuda.synchronize()` is not required (the loop is device agnostic and is unit-tested on the CPU with a stub model);
 * with accum_iter > 1 the gradient all-reduce happens only on the update micro-step (DDP `no_sync`), not on every one.
 """
@@ -55,7 +57,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
         values = values.tolist()
         for k, (it, _, lr) in enumerate(pending):
             loss_value = values[k]
-            if not math.isfinite(loss_value):
+            # (world > 1: the rank-mean decides, so that every rank raises at the same drain instead of leaving its peers in a collective)
+            if not math.isfinite(loss_value) or (reduced is not None and not math.isfinite(reduced[k])):
                 print(f"Loss is {loss_value}, stopping training")
                 raise ValueError(f"Loss is {loss_value}, stopping training")
             metric_logger.update(loss=loss_value)

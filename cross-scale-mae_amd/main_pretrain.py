@@ -9,8 +9,8 @@ Differences, all additive:
     (SURVEY.md §2 row 16); selecting them raises with that explanation;
   * the model is wrapped in `csmae_hip.parallel.DataParallel` (flat-buffer RCCL all-reduce overlapped with backward) instead of DDP,
     and the optimizer is the fused HIP AdamW with torch.optim.AdamW's state layout;
-  * W&B / TensorBoard are not wired (observability, not on the measured path — SURVEY.md §2 row 13); the reconstruction plots at
-    checkpoint epochs are (util/viz.py) and skip themselves where matplotlib is missing;
+  * W&B / TensorBoard and the matplotlib reconstruction plots at checkpoint epochs (:589-626) are not wired (observability / plotting
+    UI, not on the measured path — SURVEY.md §2 rows 13, 19);
   * `--honor_start_epoch` resumes the epoch counter (the reference ignores --start_epoch: main_pretrain.py:554-555).
 
     torchrun --nproc_per_node=8 main_pretrain.py --model mae_vit_base_MsLdCeCd --dataset_type synthetic --batch_size 128 --epochs 1
@@ -119,6 +119,25 @@ def output_dir_name(args, model_name=None):
     return name
 
 
+def protect_output_dir(output_dir, model_name, resume, distributed):
+    """Existing runs are never overwritten (main_pretrain.py:470-490).  Without --resume: a single-process run moves on to
+    `out_<name>+1`, `+2`, ... while the directory exists; a distributed run keeps its name (every rank must agree on it) and refuses
+    to start when checkpoints are already in there."""
+    import glob
+    if resume is not None:
+        return output_dir
+    if not distributed:
+        while os.path.exists(output_dir):
+            if not glob.glob(os.path.join(output_dir, "*.pth")):
+                print(f"INFO: {output_dir} already exists, but contains no .pth files. You may want to delete it.")
+            number = os.path.basename(output_dir).split("+")[-1]
+            number = int(number) + 1 if number.isdigit() else 1
+            output_dir = os.path.join(os.path.dirname(output_dir), f"out_{model_name}+{number}")
+    elif glob.glob(os.path.join(output_dir, "*.pth")):
+        raise ValueError(f"ERROR: {output_dir} already exists and contains .pth files. Checkpoints would be overwritten.")
+    return output_dir
+
+
 def main(args):
     misc.init_distributed_mode(args)
     print(f"job dir: {os.path.dirname(os.path.realpath(__file__))}")
@@ -185,6 +204,7 @@ def main(args):
         args.output_dir = f"out_{model_name}"
     if args.output_dir_base is not None:
         args.output_dir = os.path.join(args.output_dir_base, args.output_dir)
+    args.output_dir = protect_output_dir(args.output_dir, model_name, resume=args.resume, distributed=args.distributed)
     print(f"Output directory: {args.output_dir}")
     if misc.is_main_process():
         Path(args.output_dir).mkdir(parents=True, exist_ok=True)
@@ -200,36 +220,10 @@ def main(args):
         print(f"Train stats: {log_stats}")
         if args.output_dir and (epoch % 25 == 0 or epoch + 1 == args.epochs):
             misc.save_model(args=args, model=model, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler, epoch=epoch)
-            _plot_reconstructions(args, model_without_ddp, epoch)
         if args.output_dir and misc.is_main_process():
             with open(os.path.join(args.output_dir, "log.jsonl"), mode="a", encoding="utf-8") as f:
                 f.write(json.dumps(log_stats) + "\n")
     print(f"Training time {datetime.timedelta(seconds=int(time.time() - start_time))}")
-
-
-_PLOTS = {"ok": True}
-
-
-def _plot_reconstructions(args, model, epoch):
-    """The reference's reconstruction plots at checkpoint epochs (main_pretrain.py:589-626): every *.jpg under --val_img_path (or that one
-    file) through util.viz.plot_reconstruction(mask_seed=1234) into <output_dir>/plots.  Rank 0 only; skipped, with one notice, when the
-    path does not exist or matplotlib is not installed."""
-    import glob
-    if not (_PLOTS["ok"] and misc.is_main_process() and args.val_img_path and os.path.exists(args.val_img_path)):
-        return
-    from util import viz
-    paths = sorted(glob.glob(os.path.join(args.val_img_path, "*.jpg"))) if os.path.isdir(args.val_img_path) else [args.val_img_path]
-    was_training = model.training
-    model.eval()
-    try:
-        for path in paths:
-            viz.plot_reconstruction(model, path, mask_seed=1234, title=f"{args.model} - epoch {epoch} - {os.path.basename(path)}", use_noise=None,
-                                    save=True, savedir=os.path.join(args.output_dir, "plots"), show=False, device=args.device)
-    except ImportError as e:
-        _PLOTS["ok"] = False
-        print(f"reconstruction plots skipped: {e}")
-    finally:
-        model.train(was_training)
 
 
 if __name__ == "__main__":

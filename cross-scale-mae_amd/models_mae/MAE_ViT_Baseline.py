@@ -20,7 +20,7 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, engine, imgs, mask_ratio, noise, box, anchor):
         ws = engine.forward(imgs, mask_ratio, noise, box, model.training)
-        ctx.model, ctx.engine = model, engine
+        ctx.model, ctx.engine, ctx.gen = model, engine, engine.gen
         ctx.set_materialize_grads(False)
         outs = model._outputs(engine, ws, imgs.shape[0])
         ctx.mark_non_differentiable(*outs[2:])
@@ -33,7 +33,7 @@ class _StepFn(torch.autograd.Function):
         if gloss is not None:
             model = ctx.model
             grads = [p.grad for p in model.parameters() if p.requires_grad]
-            ctx.engine.backward(gloss, accumulate=any(g is not None for g in grads))
+            ctx.engine.backward(gloss, accumulate=any(g is not None for g in grads), gen=ctx.gen)
         return (None,) * 7
 
 
@@ -142,9 +142,13 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
             _check_ssim_geometry(self.input_channels)
         if dtype not in self._engines:
             self._engines[dtype] = Engine(self, self._flat, self._cfg(), dtype)
-        eng = self._engines[dtype]
-        eng.lp_fresh = False  # parameters may have been stepped / loaded since the last forward: refresh the bf16 mirror
-        return eng
+        return self._engines[dtype]
+
+    def mark_parameters_changed(self):
+        """Tell the engine that parameters were written behind torch's back (`p.data.mul_()`, raw pointers): in-place writes through
+        torch (load_state_dict, torch.optim, `p.mul_()`) are noticed by themselves, see csmae_hip.engine.FlatParams.version_stamp."""
+        if self._flat is not None:
+            self._flat.mark_changed()
 
     def _draw(self, imgs, mask_ratio, mask_seed, consistent_mask=False):
         """The reference's RNG draws, in its order (MAE_ViT_Baseline.py:301-302,251 -> MAE_ViT_Shared.py:66)."""
@@ -173,7 +177,10 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
                 anchor = self.__dict__["_anchor"] = torch.zeros((), device=imgs.device, requires_grad=True)
             return _StepFn.apply(self, eng, imgs, mask_ratio, noise, box, anchor)
         ws = eng.forward(imgs, mask_ratio, noise, box, self.training)
-        return self._outputs(eng, ws, imgs.shape[0])
+        # Outside the training fast path the outputs are fresh tensors, as in the reference.  Under autograd (the path above) the
+        # prediction / latents / embeddings are VIEWS of the engine's activation workspace: valid until the model's next forward,
+        # which overwrites them — clone what must outlive it (the loss is always a fresh scalar).
+        return tuple(o.clone() for o in self._outputs(eng, ws, imgs.shape[0]))
 
     # ---- public API (MAE_ViT_Baseline.py:299-320)
     def forward(self, imgs, mask_ratio=0.75, mask_seed=None, return_embeds=False):
@@ -209,13 +216,38 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
         return self._engine_single(x).decode(x, ids_restore)
 
     @torch.no_grad()
-    def forward_loss(self, imgs, pred, mask=None):
-        """Reconstruction loss of `--loss` on patchified `imgs` (MAE_ViT_Shared.py:269-290) through the same fused HIP loss kernels
-        `forward` uses (image read once, patchify / norm_pix / bce scaling inside the kernel).  Inference only."""
+    def forward_loss(self, target, pred, mask=None, patch_embed_psize=None, input_channels=None):
+        """Reconstruction loss of `--loss` (MAE_ViT_Shared.py:269-290), the reference's signature: `target` is a full image batch
+        [N, C, H, W] when `patch_embed_psize` and `input_channels` are given (patchified, and pixel-normalised under norm_pix_loss, by
+        `process_target` :97-111 — fused into the HIP loss kernel: the image is read once), otherwise an already patchified
+        [N, L, p*p*C] target that is compared as it is (no norm_pix step, as in the reference).  Runs the same fused HIP loss kernels
+        `forward` uses.  Inference only."""
         from csmae_hip import SSIM_KINDS, ops
         N, L, P = pred.shape
-        C, S, p = self.input_channels, self.input_size, self.patch_size
-        imgs = imgs.contiguous().float()
+        kind, ssim = self.loss, SSIM_KINDS.get(self.loss)
+        from_image = patch_embed_psize is not None and input_channels is not None
+        if from_image:
+            p, C = int(patch_embed_psize), int(input_channels)
+            norm_pix = bool(self.norm_pix_loss)
+            imgs = target.contiguous().float()
+            if imgs.dim() != 4 or imgs.shape[1] != C or imgs.shape[2] != imgs.shape[3] or imgs.shape[2] % p:
+                raise AssertionError(f"target {tuple(target.shape)} is not an (N, {C}, S, S) image batch with S % {p} == 0")  # patchify :31
+            S = imgs.shape[2]
+        else:
+            if ssim is not None:  # forward_loss_ssim un-patchifies with kwargs['patch_embed_psize'] = None (MAE_ViT_Shared.py:181-185)
+                raise TypeError(f"loss={self.loss!r} compares images: pass patch_embed_psize and input_channels (the reference fails in "
+                                "unpatchify(x, None, None), MAE_ViT_Shared.py:181)")
+            if target.shape != pred.shape:
+                raise RuntimeError(f"patchified target {tuple(target.shape)} does not match pred {tuple(pred.shape)}")
+            # compared as it is (no process_target, no pixel normalisation): every [P] row is handed to the fused kernel as a
+            # one-patch "image" with P channels (a reshape, nothing is copied or permuted), so any feature size works
+            norm_pix, p, C, S = False, 1, P, 1
+            imgs = target.contiguous().float().reshape(N * L, P, 1, 1)
+            pred = pred.reshape(N * L, 1, P)
+            mask = None if mask is None else mask.reshape(N * L, 1)
+            N, L = N * L, 1
+        if (S // p) ** 2 != L or P != p * p * C:
+            raise RuntimeError(f"pred {tuple(pred.shape)} does not match a {S}x{S} image with {p}-pixel patches and {C} channels")
         dev = imgs.device
         full = torch.zeros(N, L + 1, P, device=dev, dtype=torch.float32)  # the kernels index predictions with the cls row in place
         full[:, 1:, :] = pred
@@ -223,20 +255,19 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
         rowloss = torch.empty(N * L, device=dev, dtype=torch.float32)
         mm = None
         m = torch.ones(N, L, device=dev, dtype=torch.float32) if mask is None else mask.to(torch.float32).contiguous()
-        kind, ssim = self.loss, SSIM_KINDS.get(self.loss)
         if ssim is not None:  # MAE_ViT_Shared.py:165-267 (no mask = every patch compared, :187-189)
             _check_ssim_geometry(C)
             kind = ssim[0]
             ws = torch.empty(ops.ssim_workspace_floats(N, C, S, p, ssim[1]), device=dev, dtype=torch.float32)
             terms = torch.empty(2, device=dev, dtype=torch.float32)
-            ops.ssim_fwd(ssim[1], self.norm_pix_loss, imgs, None, full, m, ws, terms, N, N, C, S, p)
+            ops.ssim_fwd(ssim[1], norm_pix, imgs, None, full, m, ws, terms, N, N, C, S, p)
         if kind == "bce":
             mm = torch.empty(2, device=dev, dtype=torch.float32)
-            ops.target_minmax(imgs, None, torch.empty(N * L * 2, device=dev, dtype=torch.float32), mm, N, N, C, S, p, self.norm_pix_loss)
+            ops.target_minmax(imgs, None, torch.empty(N * L * 2, device=dev, dtype=torch.float32), mm, N, N, C, S, p, norm_pix)
         if kind == "none":
             rowloss.zero_()
         else:
-            ops.recon_loss_fwd(kind, self.norm_pix_loss, imgs, None, full, mm, rowloss, N, N, C, S, p)
+            ops.recon_loss_fwd(kind, norm_pix, imgs, None, full, mm, rowloss, N, N, C, S, p)
         losses = torch.zeros(8, device=dev, dtype=torch.float32)
         ops.loss_finalize(N * L, 1, rowloss, m, 1.0, losses)
         if ssim is not None:

@@ -189,11 +189,52 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
     return torch.norm(torch.stack([torch.norm(g, norm_type) for g in grads]), norm_type)
 
 
+def clip_grad_norm_(parameters, max_norm):
+    """`torch.nn.utils.clip_grad_norm_(parameters, max_norm)` (util/misc.py:314-316; `max_norm=None`: `get_grad_norm_`, :318) -> the total
+    2-norm as a 0-dim tensor, gradients scaled in place by min(1, max_norm / (norm + 1e-6)).  When the gradients are the engine's
+    views of the flat gradient buffer — the case on the MI355X path — this is two streaming HIP kernels over that one buffer with the
+    coefficient read from device memory (no host sync, no ~250-tensor foreach); anything else (a foreign model, CPU tests of the
+    loop) goes through torch."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    params = [p for p in parameters if p.grad is not None]
+    flat = None
+    if params and params[0].is_cuda:
+        from csmae_hip.engine import FlatParams
+        flat = FlatParams.owner_of(params[0])
+        if flat is not None:
+            g0, views = flat.g.data_ptr(), 0
+            for p in params:
+                name = flat._by_id.get(id(p))
+                if name is None or p.grad.data_ptr() != g0 + flat.slots[name][0] * 4:
+                    flat = None
+                    break
+                views += 1
+            # every parameter of the model that has a gradient must be in the call (the buffer is normed as a whole)
+            if flat is not None and views != sum(1 for q in flat.params.values() if q.grad is not None):
+                flat = None
+    if flat is None:
+        if max_norm is None:
+            return get_grad_norm_(params)
+        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+    from csmae_hip import ops
+    scratch = flat.__dict__.get("_norm_scratch")
+    if scratch is None:
+        scratch = flat.__dict__["_norm_scratch"] = torch.empty(1024 + 2, device=flat.g.device, dtype=torch.float32)
+    out = scratch[1024:]
+    ops.clip_grad_norm(flat.g[: flat.total], -1.0 if max_norm is None else float(max_norm), scratch, out)
+    return out[0].clone()
+
+
 class NativeScalerWithGradNormCount:
     """Same callable / state_dict contract as the reference (util/misc.py:299-335).  The MI355X path computes in bf16 (or fp32),
     which needs no loss scaling, so the wrapped GradScaler is disabled: backward -> optional clip -> optimizer.step().
     The reference computes the global gradient norm on every update and the engine ignores it; here it is only computed when
-    clipping is requested or `compute_grad_norm=True` (it costs one extra read of every gradient)."""
+    clipping is requested or `compute_grad_norm=True` (it costs one extra read of every gradient) — by HIP kernels over the flat
+    gradient buffer (`clip_grad_norm_` above).
+    fp16 + loss scaling (what the reference's `torch.cuda.amp.autocast()` + GradScaler runs, engine_pretrain.py:52, util/misc.py:303)
+    is deliberately not emulated: the throughput path is bf16 (fp32 exponent range: no overflow to scale away), the parity path is
+    fp32; an fp16 mode would add a third numerics mode that matches neither the fp32 oracle nor the bf16 MFMA path."""
     state_dict_key = "amp_scaler"
 
     def __init__(self, compute_grad_norm=False):
@@ -206,9 +247,9 @@ class NativeScalerWithGradNormCount:
         if update_grad:
             if clip_grad is not None:
                 assert parameters is not None
-                norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
+                norm = clip_grad_norm_(parameters, clip_grad)
             elif self.compute_grad_norm:
-                norm = get_grad_norm_(parameters)
+                norm = clip_grad_norm_(parameters, None)
             optimizer.step()
         return norm
 

@@ -1,18 +1,19 @@
-"""Reconstruction tools around the pre-training path (reference util/viz.py:27-316): checkpoint -> model, image file -> normalised
+"""Reconstruction helpers around the pre-training path (reference util/viz.py:27-206): checkpoint -> model, image file -> normalised
 array, one masked forward of a single image -> (original, masked input, reconstruction, reconstruction of the masked patches,
-reconstruction pasted into the visible patches), and the three-panel figure main_pretrain.py draws every 25 epochs (:589-626).
+reconstruction pasted into the visible patches).
 
 The model forward is the HIP path (`model(x, mask_ratio=, mask_seed=)`); everything else here is host-side array handling.
-Drawing needs matplotlib, which this image does not ship: `plot_image` / `plot_reconstruction` import it lazily and say so."""
+The reference's matplotlib figures (`plot_image`, `plot_reconstruction`, `add_noise`, the dataset-wide sweeps, util/viz.py:123-138,
+208-316) are plotting UI — SURVEY §2 row 19, out of scope — and are not rebuilt: `run_one_image` + `util.metrics.calc_metric` give the
+arrays and scores a figure would show."""
 import os
 import re
-from typing import Optional, Union
+from typing import Optional
 
 import numpy as np
 import torch
 
 import models_mae
-from util import metrics
 from util.gpu_input import resized_crop_box
 
 # per-channel statistics the reference hard-codes for its plots (util/viz.py:23-24)
@@ -71,20 +72,6 @@ def prepare_image(image_uri, img_size, random_crop=False, crop_seed=None, resamp
     return (np.array(img) / 255.0 - image_mean) / image_std
 
 
-def add_noise(image, noise_type="gaussian", noise_param=0.1):
-    if not isinstance(image, torch.Tensor):
-        image = torch.tensor(image)
-    if noise_type == "gaussian":
-        noise = torch.randn_like(image) * noise_param
-    elif noise_type == "poisson":
-        noise = torch.poisson(torch.ones_like(image) * noise_param)
-    elif noise_type == "s&p":
-        noise = torch.bernoulli(torch.ones_like(image) * noise_param)
-    else:
-        raise ValueError("Invalid noise type")
-    return image + noise.to(image.device)
-
-
 @torch.no_grad()
 def run_one_image(img, model, mask_seed: Optional[int] = None, **kwargs):
     """One [H, W, C] normalised image through `model(x, mask_ratio=model.mask_ratio, mask_seed=)` -> five [1, H, W, C] CPU tensors in
@@ -106,69 +93,3 @@ def run_one_image(img, model, mask_seed: Optional[int] = None, **kwargs):
     xm = x * (1 - mask)
     ym = y * mask
     return x, xm, y, ym, xm + ym
-
-
-def _pyplot():
-    try:
-        import matplotlib
-        matplotlib.use("Agg", force=False)
-        import matplotlib.pyplot as plt
-        return plt
-    except ImportError as e:
-        raise ImportError("util.viz plotting needs matplotlib, which is not installed in this image; run_one_image / util.metrics "
-                          "give the arrays and scores without it") from e
-
-
-def plot_image(image, ax=None, title="", figsize=4, show=False):
-    plt = _pyplot()
-    if image.shape[0] == 1:
-        image = image.squeeze(dim=0)
-    assert len(image.shape) == 3, "image should be (H, W, C)"
-    if ax is None:
-        _, ax = plt.subplots(figsize=(figsize, figsize))
-    if image.dtype != np.uint8:
-        image = torch.clip(image * 255, 0, 255).int()
-    ax.imshow(image)
-    ax.set_title(title)
-    ax.axis("off")
-    if show:
-        plt.show()
-
-
-def plot_reconstruction(models: Union[dict, torch.nn.Module], image, image_name: Optional[str] = None, comp_metric: str = "ssim",
-                        title: Optional[str] = None, figsize: int = 10, savedir: str = "./plots/", save: bool = False, show: bool = True,
-                        **kwargs):
-    """Original | masked input | reconstruction (with `comp_metric` against the original in the panel title), one row per model;
-    returns the rendered figure as an [H, W, 3] uint8 array (util/viz.py:231-316)."""
-    plt = _pyplot()
-    if not isinstance(models, dict):
-        models = {"model": models}
-    plt.clf()
-    fig, axs = plt.subplots(len(models), 3, figsize=(figsize, len(models) * figsize / 3.0))
-    savesubdir = None
-    if title is not None:
-        if image_name is not None:
-            savesubdir = title_to_fname(title)
-            title = f"{title} - {image_name}"
-        fig.suptitle(title)
-    for k, (name, model) in enumerate(models.items()):
-        img = prepare_image(image, model.input_size, **kwargs) if isinstance(image, str) else image.copy()
-        x, xm, y, _, _ = run_one_image(img, model, **kwargs)
-        score = metrics.calc_metric(x, y, comp_metric)
-        for i, (ti, im) in enumerate({"Original": x, "Input (Masked)": xm, f"{name} ({comp_metric.upper()}: {score:<.3f})": y}.items()):
-            plot_image(im, axs[k, i] if len(models) > 1 else axs[i], ti)
-    plt.tight_layout()
-    if save:
-        if title is not None:
-            if savesubdir is not None:
-                savedir = os.path.join(savedir, savesubdir)
-            os.makedirs(savedir, exist_ok=True)
-            plt.savefig(os.path.join(savedir, f"plot_img_{title_to_fname(title)}.png"))
-        else:
-            print("INFO: Skipped saving because title was not provided")
-    if show:
-        plt.show()
-    fig.canvas.draw()
-    data = np.asarray(fig.canvas.buffer_rgba())[..., :3].copy()
-    plt.close(fig)
-    return data

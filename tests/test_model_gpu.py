@@ -202,7 +202,7 @@ def test_ssim_family_standalone_forward_loss_and_bf16_step():
     mask = (torch.rand(2, 121, generator=g) > 0.25).float()
     tgt = O.recon_target(imgs, 16, 3, False)
     for mk in (mask, None):
-        got = m.forward_loss(imgs.cuda(), pred.cuda(), None if mk is None else mk.cuda())
+        got = m.forward_loss(imgs.cuda(), pred.cuda(), None if mk is None else mk.cuda(), 16, 3)
         assert rel(got, O.loss_fn("mse_ms_ssim", tgt, pred, mk, 16, 3)) < LOSS_RTOL
     m.compute_dtype = torch.bfloat16   # the MFMA path: same loss head in fp32 behind bf16 GEMMs
     m32 = models_mae.MAE_ViT_Baseline(**MICRO, input_size=176, patch_size="16", loss="mse_ms_ssim").cuda().train()
@@ -365,7 +365,7 @@ def test_standalone_encoder_decoder_loss_match_oracle():
     pred_o, emb_o = O.decoder(sd, cfg, lat_o, ids_o)
     assert pred.shape == pred_o.shape and emb.shape == emb_o.shape
     assert torch.allclose(pred.cpu(), pred_o, atol=3e-4, rtol=1e-4) and torch.allclose(emb.cpu(), emb_o, atol=3e-4, rtol=1e-4)
-    loss = m.forward_loss(imgs, pred, mask)
+    loss = m.forward_loss(imgs, pred, mask, m.patch_embed.patch_size[0], m.input_channels)   # MAE_ViT_Baseline.py:309-315
     want = O.loss_fn("mse", O.recon_target(imgs.cpu(), 16, 3, False), pred_o, mask_o)
     assert abs(float(loss) - float(want)) <= 1e-4 * abs(float(want)), (float(loss), float(want))
     # the training entry point is unaffected by the stand-alone calls
@@ -609,3 +609,30 @@ def test_eval_mode_uses_running_statistics_like_the_oracle():
     with torch.no_grad():
         otrain = O.forward(osd, cfg, T(d["imgs"]), dr["noise"][0], dr["noise"][1], dr["box"], 0.75, dict(bn), training=True)
     assert abs(float(otrain["loss_cd"]) - float(oout["loss_cd"])) > 1e-6
+
+
+def test_forward_loss_reference_signature_against_reference_fixture():
+    """`forward_loss(target, pred, mask=None, patch_embed_psize=None, input_channels=None)` called the reference's two ways
+    (MAE_ViT_Shared.py:269-290; call site MAE_ViT_Baseline.py:309-315): image target + patch size + channels (process_target inside),
+    and an already patchified target of any feature size compared as it is.  Expected values: tests/golden/patch_loss.npz, produced
+    by the reference's own forward_loss (oracle/gen_golden.py:g_patch_loss)."""
+    import models_mae
+    d = load("patch_loss.npz")
+    C = lambda k: T(d[k]).cuda()
+    imgs, pred, mask = C("loss_imgs"), C("loss_pred"), C("loss_mask")
+    for kind in ("mse", "l2", "mae", "l1", "bce"):
+        m = models_mae.MAE_ViT_Baseline(**MICRO, input_size=32, patch_size="16", loss=kind).cuda().eval()
+        got = m.forward_loss(imgs, pred, mask, 16, 3)
+        assert rel(got, d[f"loss_{kind}_masked"]) < LOSS_RTOL, kind
+        got = m.forward_loss(imgs, pred, None, 16, 3)
+        assert rel(got, d[f"loss_{kind}_nomask"]) < LOSS_RTOL, kind
+        got = m.forward_loss(C(f"raw_t_{kind}"), C(f"raw_p_{kind}"))          # patchified target, feature size 20: no process_target
+        assert rel(got, d[f"loss_{kind}_raw"]) < LOSS_RTOL, kind
+        tgt = m.patchify(imgs, 16, 3)                                           # the same loss through the patchified entry
+        assert rel(m.forward_loss(tgt, pred, mask), d[f"loss_{kind}_masked"]) < LOSS_RTOL, kind
+    m = models_mae.MAE_ViT_Baseline(**MICRO, input_size=32, patch_size="16", loss="mse", norm_pix_loss=True).cuda().eval()
+    assert rel(m.forward_loss(imgs, pred, mask, 16, 3), d["loss_mse_normpix"]) < LOSS_RTOL
+    # norm_pix_loss only acts inside process_target: a patchified target is taken as it is (MAE_ViT_Shared.py:280-281)
+    assert rel(m.forward_loss(C("target_normpix"), pred, mask), d["loss_mse_normpix"]) < LOSS_RTOL
+    with pytest.raises(TypeError, match="patch_embed_psize"):
+        models_mae.MAE_ViT_Baseline(**MICRO, input_size=176, patch_size="16", loss="ssim").cuda().forward_loss(pred, pred)

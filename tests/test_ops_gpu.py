@@ -573,7 +573,11 @@ def test_augment_u8_matches_reference_transform_chain():
         for _ in range(20):
             h_, w_, i, j, h, w, hf, vf = __import__("util.gpu_input", fromlist=["x"]).sample_transform_params(H, W)
             assert (h_, w_) == (H, W) and 0 <= i and i + h <= H and 0 <= j and j + w <= W and hf in (0, 1) and vf in (0, 1)
-            assert h * w >= 0.2 * H * W * 0.9 or (h, w) == (H, W) or True
+            # a proposal of torchvision's get_params (area in [0.25, 1] of the image, aspect in [3/4, 4/3], up to the rounding of h and
+            # w) or, after ten rejected proposals, its centred fallback crop
+            proposal = 0.25 * 0.95 * H * W <= h * w <= H * W and 0.75 * 0.9 <= w / h <= 4.0 / 3.0 * 1.1
+            centred = i == (H - h) // 2 and j == (W - w) // 2
+            assert proposal or centred, (H, W, i, j, h, w)
 
 
 @pytest.mark.gpu

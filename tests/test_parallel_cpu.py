@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import models_mae
-        from csmae_hip.parallel import GradSync, bucket_ranges
+        from csmae_hip.parallel import FlatBuffers, GradSync, bucket_ranges
         micro = dict(dim_model=128, encoder_num_layers=6, encoder_num_heads=2, decoder_embed_dim=64, decoder_num_layers=2, decoder_num_heads=2)
         torch.manual_seed(0)
         m = models_mae.MAE_ViT_MsLdCeCd(**micro, input_size=64, predictor_hidden_size=128)
@@ -69,6 +69,20 @@ def _worker(rank, world, port, q):
         nbt = torch.tensor(rank, dtype=torch.long)
         sync.broadcast([p, nbt])
         assert float(p.sum()) == 0.0 and int(nbt) == 0
+        # the per-forward BatchNorm-buffer broadcast is ONE message: running_mean, running_var (fp32) and num_batches_tracked (int64)
+        # live in one byte buffer; in-place updates of the module's buffers land in it, a broadcast of it reaches the module
+        bn = m.predictor[1]
+        fb = FlatBuffers(m)
+        assert fb.still_homed() and [n for n, _ in fb.items] == ["predictor.1.running_mean", "predictor.1.running_var", "predictor.1.num_batches_tracked"]
+        bn.running_mean.fill_(1.0 + rank)
+        bn.running_var.mul_(2.0 + rank)
+        bn.num_batches_tracked.add_(5 + rank)
+        sync.broadcast([fb.raw])
+        assert float(bn.running_mean.mean()) == 1.0 and float(bn.running_var.mean()) == 2.0 and int(bn.num_batches_tracked) == 5
+        m.load_state_dict(m.state_dict())      # copies in place: still homed
+        assert fb.still_homed()
+        # the update-gate slot behind the last parameter rides in the tail range
+        assert bucket_ranges(slots, names, n_encoder=6, tail_extra=8)[0][2] == total + 8
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
