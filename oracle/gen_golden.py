@@ -585,6 +585,84 @@ def g_vitb():
     np.savez_compressed(os.path.join(OUT, "vitb_anchor.npz"), **d)
 
 
+
+# ------------------------------------------------------------------------------- G10 full-size geometries of BASELINE.json configs[1..4]
+FULLSIZE = {  # tag -> (geometry kwargs, input size, patch, channels, N)
+    "vitb16_224": (dict(dim_model=768, encoder_num_layers=12, encoder_num_heads=12, decoder_embed_dim=512, decoder_num_layers=8, decoder_num_heads=16), 224, 16, 3, 4),
+    "vitl16_224": (dict(dim_model=1024, encoder_num_layers=24, encoder_num_heads=16, decoder_embed_dim=512, decoder_num_layers=8, decoder_num_heads=16), 224, 16, 3, 2),
+    "vitl16_256c4": (dict(dim_model=1024, encoder_num_layers=24, encoder_num_heads=16, decoder_embed_dim=512, decoder_num_layers=8, decoder_num_heads=16), 256, 16, 4, 2),
+    "vith14_224": (dict(dim_model=1280, encoder_num_layers=32, encoder_num_heads=16, decoder_embed_dim=512, decoder_num_layers=8, decoder_num_heads=16), 224, 14, 3, 2),
+}
+FULLSIZE_WEIGHTS = ("patch_embed.proj.weight", "encoder.0.attn.qkv.weight", "decoder.7.mlp.fc2.weight", "predictor.0.weight", "mask_token")
+
+
+def fullsize_inputs(tag):
+    """Seeded inputs of the full-size fixtures (regenerated, not stored: 2.4 MB of incompressible noise per config).  The fixture
+    carries a checksum so that a torch whose CPU generator differs is reported as such."""
+    geom, S, p, C, N = FULLSIZE[tag]
+    g = torch.Generator().manual_seed(1000 + sorted(FULLSIZE).index(tag))
+    L = (S // p) ** 2
+    return torch.randn(N, C, S, S, generator=g), [torch.rand(N, L, generator=g), torch.rand(N, L, generator=g)]
+
+
+def g_fullsize(tags=None):
+    """MAE_ViT_MsLdCeCd at the geometries BASELINE.json's configs[1..4] are quoted on (ViT-B/16 224^2; ViT-L/16 224^2; ViT-L/16 256^2
+    4-band; ViT-H/14 224^2), small batches, seeded default init, one forward + backward of the REFERENCE: every loss term, the masks,
+    and sum / sum of squares of every parameter gradient."""
+    d, meta = {}, {}
+    for tag in (tags or FULLSIZE):
+        geom, S, p, C, N = FULLSIZE[tag]
+        torch.manual_seed(0)
+        with quiet():
+            m = models_mae.MAE_ViT_MsLdCeCd(**geom, input_size=S, patch_size=str(p), input_channels=C, loss="mse", device="cpu")
+        m.train()
+        imgs, noise = fullsize_inputs(tag)
+        rec = dict(recon=[], ce=[], cd=[])
+        ofl = m.forward_loss
+        m.forward_loss = lambda *a, _o=ofl, **k: (lambda r: (rec["recon"].append(float(r)), r)[1])(_o(*a, **k))
+        ocd = getattr(m, "_MAE_ViT_MsLdCeCd__forward_loss_cd")
+        setattr(m, "_MAE_ViT_MsLdCeCd__forward_loss_cd", lambda *a, _o=ocd, **k: (lambda r: (rec["cd"].append(float(r)), r)[1])(_o(*a, **k)))
+        orig_nt = ref_contrast.NTXentLoss.forward
+        ref_contrast.NTXentLoss.forward = lambda self, a, b: (lambda r: (rec["ce"].append(float(r)), r)[1])(orig_nt(self, a, b))
+        draws = []
+        try:
+            torch.manual_seed(4242)   # the crop box comes from the global CPU generator (MAE_ViT_MsLd.py:52)
+            with record_rand(draws, inject=noise):
+                out = m(imgs, mask_ratio=0.75, return_embeds=True)
+        finally:
+            ref_contrast.NTXentLoss.forward = orig_nt
+        out[0].backward()
+        assert len(draws) == 2 and torch.equal(draws[0], noise[0]) and torch.equal(draws[1], noise[1])
+        names = sorted(n for n, q in m.named_parameters() if q.grad is not None)
+        grads = dict(m.named_parameters())
+        d[f"{tag}_mask"] = npy(out[2]).astype(np.uint8)
+        d[f"{tag}_noise0"], d[f"{tag}_noise1"] = npy(noise[0]), npy(noise[1])
+        d[f"{tag}_gradnames"] = np.array(names)
+        d[f"{tag}_gradsq"] = np.array([grads[n].grad.double().pow(2).sum().item() for n in names])
+        d[f"{tag}_gradsum"] = np.array([grads[n].grad.double().sum().item() for n in names])
+        d[f"{tag}_pred_head"] = npy(out[1][:, :2, :48])
+        d[f"{tag}_g_mask_token"] = npy(m.mask_token.grad)
+        d[f"{tag}_g_decoder_pred_bias"] = npy(m.decoder_pred.bias.grad)
+        d[f"{tag}_g_cls_token"] = npy(m.cls_token.grad)
+        meta[tag] = dict(geom=geom, input_size=S, patch=p, channels=C, N=N, loss=float(out[0]), recon=rec["recon"], ce=rec["ce"][0], cd=rec["cd"][0],
+                         box=[int(v) for v in ref_stubs.RandomResizedCrop.last_box],
+                         pred_sum=[out[1].double().sum().item(), out[1].double().abs().sum().item()],
+                         enc_sum=[t.double().abs().sum().item() for t in out[3]], dec_sum=[t.double().abs().sum().item() for t in out[4]],
+                         nograd=[n for n, q in m.named_parameters() if q.requires_grad and q.grad is None],
+                         imgs_checksum=checksum(imgs)[:3], weights={k: checksum(v)[:3] for k, v in m.state_dict().items() if k in FULLSIZE_WEIGHTS},
+                         bn_running_mean_sum=float(m.predictor[1].running_mean.double().sum()))
+        _print(f"fullsize {tag}: loss {float(out[0]):.6f} recon {rec['recon']} ce {rec['ce'][0]:.6f} cd {rec['cd'][0]:.6f} box {meta[tag]['box']}")
+        del m, out, grads
+    if tags:   # partial regeneration: merge into the existing files
+        old = dict(np.load(os.path.join(OUT, "fullsize.npz")))
+        old.update(d)
+        d = old
+        om = json.load(open(os.path.join(OUT, "fullsize.json")))
+        om.update(meta)
+        meta = om
+    np.savez_compressed(os.path.join(OUT, "fullsize.npz"), **d)
+    json.dump(meta, open(os.path.join(OUT, "fullsize.json"), "w"), indent=1)
+
 def main():
     torch.set_num_threads(8)
     with quiet():
@@ -599,6 +677,7 @@ def main():
     g_crop()
     g_model_micro()
     g_vitb()
+    g_fullsize()
     for f in sorted(os.listdir(OUT)):
         _print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
 

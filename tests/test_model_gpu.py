@@ -374,36 +374,83 @@ def test_standalone_encoder_decoder_loss_match_oracle():
     assert torch.isfinite(out[0])
 
 
-@pytest.mark.parametrize("name,kw,n", [("mae_vit_large_MsLdCeCd", dict(input_size=256, patch_size="16", input_channels=4), 2),
-                                       ("mae_vit_huge_MsLdCeCd", dict(input_size=224, patch_size="14"), 2)])
-def test_large_and_huge_presets_one_step(name, kw, n):
-    """BASELINE.json configs 4 / 5 geometries (4-band 256^2 ViT-L; ViT-H/14: hd = 80, P = 588 not a multiple of 8) through the
-    throughput kernels: finite gradients, bf16 loss within 2e-2 of the fp32 engine, one fused AdamW step."""
-    import models_mae
+BF16_LOSS_RTOL = 2e-3    # bf16 MFMA path vs the reference, total loss (measured 1e-4 .. 6e-4 over the four geometries; 3x headroom)
+BF16_GRAD_COS = 0.999    # cosine of every parameter gradient against the oracle's (measured >= 0.9995 for tensors with a non-zero gradient)
+
+
+@pytest.mark.parametrize("tag", ["vitb16_224", "vitl16_224", "vitl16_256c4", "vith14_224"])
+def test_fullsize_geometry_vs_reference_and_oracle(tag):
+    """MAE_ViT_MsLdCeCd at the geometries BASELINE.json's configs[1..4] are quoted on — ViT-B/16 224^2 (L = 196, Te = 50, Td = 197),
+    ViT-L/16 224^2, ViT-L/16 256^2 4-band, ViT-H/14 224^2 (hd = 80, P = 588) — against (a) the REFERENCE's outputs on the same seeded
+    weights, images, noise and crop box (tests/golden/fullsize.*) and (b) the oracle's full gradients, elementwise.
+    fp32 engine: every loss term within 1e-4 relative, masks bit-exact.  bf16 MFMA engine: total loss within BF16_LOSS_RTOL, every
+    parameter gradient's cosine against the oracle >= BF16_GRAD_COS."""
+    import csmae_oracle as O
+    import fullsize_util as F
     from csmae_hip.optim import FusedAdamW, add_weight_decay
-    torch.manual_seed(0)
-    m = models_mae.__dict__[name](**kw).cuda().train()
-    x = torch.randn(n, kw.get("input_channels", 3), kw["input_size"], kw["input_size"], device="cuda")
-    losses = {}
-    for dt in (torch.float32, torch.bfloat16):
-        m.compute_dtype = dt
+    meta, d = F.load(tag)
+    imgs = F.inputs(tag, meta)
+    m = F.seeded_model(meta)
+    osd = O.trainable_copy({k: v.detach().clone() for k, v in m.state_dict().items()})
+    cfg = O.make_cfg(input_size=meta["input_size"], input_channels=meta["channels"], patch_size=meta["patch"], variant="MsLdCeCd", **meta["geom"])
+    noise, box = [T(d["noise0"]), T(d["noise1"])], tuple(meta["box"])
+    oout = O.forward(osd, cfg, imgs, noise[0], noise[1], box)
+    oout["loss"].backward()
+    m = m.cuda().train()
+    x = imgs.cuda()
+    names = [str(n) for n in d["gradnames"]]
+    params = dict(m.named_parameters())
+    for dtype in (torch.float32, torch.bfloat16):
+        m.compute_dtype = dtype
         m.zero_grad(set_to_none=True)
-        torch.manual_seed(1)
+        m._test_draws = dict(noise=noise, box=box)
         loss, pred, mask = m(x, mask_ratio=0.75)
         loss.backward()
+        L = m._engines[dtype].ws.losses.cpu()
+        assert np.array_equal(mask.cpu().numpy().astype(np.uint8), d["mask"])                     # random_masking: bit-exact
+        terms = dict(total=(L[0], meta["loss"]), recon_orig=(L[1], meta["recon"][0]), recon_crop=(L[2], meta["recon"][1]),
+                     cd=(L[3], meta["cd"]), ce=(L[4], meta["ce"]))
+        errs = {k: rel(a, b) for k, (a, b) in terms.items()}
+        if dtype == torch.float32:
+            assert max(errs.values()) < LOSS_RTOL, (tag, errs)
+            np.testing.assert_allclose(pred[:, :2, :48].detach().cpu().numpy(), d["pred_head"], rtol=1e-3, atol=3e-5)
+            for n, sq in zip(names, d["gradsq"]):                                                  # the reference's own gradients
+                got = params[n].grad.double().pow(2).sum().item()
+                assert abs(got - sq) <= 2e-3 * sq + 1e-14, (tag, n, got, sq)
+            assert sorted(n for n, p in params.items() if p.requires_grad and p.grad is None) == sorted(meta["nograd"])
+            worst = 0.0
+            for n, p in params.items():                                                            # the oracle's, elementwise
+                if p.grad is None:
+                    continue
+                ref = osd[n].grad
+                scale = ref.abs().max().item()
+                np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=3e-3, atol=3e-4 * scale + 1e-9, err_msg=f"{tag} {n}")
+        else:
+            assert errs["total"] < BF16_LOSS_RTOL and max(errs.values()) < 3 * BF16_LOSS_RTOL, (tag, errs)
+            worst = ("", 1.0)
+            for n, p in params.items():
+                if p.grad is None:
+                    continue
+                ref = osd[n].grad.flatten().double()
+                if float(ref.norm()) < 1e-7 * ref.numel() ** 0.5:     # (mathematically zero gradients — key biases: softmax shift invariance)
+                    continue
+                cos = float(torch.nn.functional.cosine_similarity(p.grad.flatten().double().cpu(), ref, dim=0))
+                if cos < worst[1]:
+                    worst = (n, cos)
+            assert worst[1] >= BF16_GRAD_COS, (tag, worst)
+            print(f"[fullsize {tag}] bf16 loss errors {({k: f'{v:.1e}' for k, v in errs.items()})}, worst gradient cosine {worst}")
         assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
-        losses[dt] = float(loss.detach())
-    FusedAdamW(add_weight_decay(m, 0.05), lr=1e-4, betas=(0.9, 0.95)).step()
+    FusedAdamW(add_weight_decay(m, 0.05), lr=1e-4, betas=(0.9, 0.95)).step()                      # one fused AdamW step at this geometry
     torch.cuda.synchronize()
-    assert abs(losses[torch.bfloat16] - losses[torch.float32]) <= 2e-2 * abs(losses[torch.float32]), losses
+    assert all(torch.isfinite(p).all() for p in m.parameters())
 
 
 def test_full_size_vitb_224_n128_properties():
     """BASELINE.json configs[1] at full size (ViT-B/16 MsLdCeCd, 224^2, 128 images, bf16 MFMA path) through properties that need no
     oracle run: masking indices are permutations in noise order with exactly L - keep masked patches per row; the step is deterministic
     (two runs on the same draws: bit-identical loss and gradients — every reduction is ordered); the total is the sum of its terms;
-    the backward is exactly linear in the incoming gradient for a power-of-two factor; and the fp32 engine agrees within the bf16
-    tolerance written for the small cases (2e-2)."""
+    the backward is exactly linear in the incoming gradient for a power-of-two factor; and the fp32 engine — itself pinned to the
+    reference at this geometry by test_fullsize_geometry_vs_reference_and_oracle — agrees within BF16_LOSS_RTOL / BF16_GRAD_COS."""
     import models_mae
     torch.manual_seed(0)
     m = models_mae.mae_vit_base_MsLdCeCd(input_size=224, patch_size="16", loss="mse", device="cuda").cuda().train()
@@ -446,10 +493,10 @@ def test_full_size_vitb_224_n128_properties():
     # fp32 engine on the same draws
     lf, _, ids_f, _, gf = run(torch.float32)
     assert torch.equal(ids_f, ids)
-    assert abs(float(la) - float(lf)) <= 2e-2 * abs(float(lf))
+    assert abs(float(la) - float(lf)) <= BF16_LOSS_RTOL * abs(float(lf)), (float(la), float(lf))
     for n in names:
         cos = torch.nn.functional.cosine_similarity(ga[n].flatten().double(), gf[n].flatten().double(), dim=0)
-        assert cos > 0.98, (n, float(cos))
+        assert cos > BF16_GRAD_COS, (n, float(cos))
 
 
 def test_metrics_ssim_on_gpu_match_oracle():
