@@ -27,17 +27,18 @@ _SIGNATURES = {
     "csmae_gemm_force_tile": [I],
     "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
-    "csmae_layernorm_fwd": [I, L, I, P, P, P, F, P, P, P, P, P],
-    "csmae_layernorm_bwd": [I, I, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P],
+    "csmae_layernorm_fwd": [I, I, L, I, P, P, P, F, P, P, P, P, P],
+    "csmae_layernorm_bwd": [I, I, I, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P],
+    "csmae_ln_param_reduce": [I, L, I, P, L, L, P, P, P],
     "csmae_bnrelu_fwd": [I, I, I, I, P, P, P, F, F, P, P, P, P, P, P, I, P],
     "csmae_bnrelu_bwd": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "csmae_crop_resize": [L, I, P, P, P, P],
     "csmae_mask_sort": [L, I, I, P, P, P, P, P, P],
     "csmae_patch_gather": [I, L, I, I, I, I, I, P, P, P, P, L, P],
-    "csmae_embed_assemble": [L, I, I, P, P, P, P, P, P],
-    "csmae_embed_assemble_bwd": [I, L, I, I, P, P, P, P],
-    "csmae_unshuffle_fwd": [L, I, I, I, P, P, P, P, P, P],
-    "csmae_unshuffle_bwd": [I, L, I, I, I, P, P, P, P, P],
+    "csmae_embed_assemble": [I, L, I, I, P, P, P, P, P, P],
+    "csmae_embed_assemble_bwd": [I, I, L, I, I, P, P, P, P],
+    "csmae_unshuffle_fwd": [I, L, I, I, I, P, P, P, P, P, P],
+    "csmae_unshuffle_bwd": [I, I, L, I, I, I, P, P, P, P, P],
     "csmae_rows_gather": [I, L, I, P, L, L, L, P, P],
     "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],
     "csmae_target_minmax": [I, L, I, I, I, I, P, P, P, P, P],
@@ -58,6 +59,7 @@ _SIGNATURES = {
     "csmae_gate_accumulate": [P, P, I, P],
     "csmae_clip_grad_norm": [L, P, F, P, P, P],
     "csmae_cast_f32_to_bf16": [L, P, P, P],
+    "csmae_cast_bf16_to_f32": [L, P, P, P],
     "csmae_colsum": [I, L, I, P, L, P, P],
 }
 

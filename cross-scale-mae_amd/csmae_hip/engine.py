@@ -125,6 +125,7 @@ class Workspace:
         D, Dd, L, Pp = c["D"], c["Dd"], c["L"], eng.Pp
         f32 = dict(device=dev, dtype=torch.float32)
         lp = dict(device=dev, dtype=T)
+        rs = dict(device=dev, dtype=eng.res_dtype)   # the residual stream x / x_mid (and its gradient): fp32, or bf16 in throughput mode
         E = torch.empty
         self.imgs_crop = E(N, c["C"], c["S"], c["S"], **f32) if V == 2 else None
         self.box = torch.zeros(4, device=dev, dtype=torch.int32)
@@ -136,12 +137,13 @@ class Workspace:
         self.tok = E(B2 * max(keep, 1), D, **f32)
 
         def stack(nl, M, Dm, H):
-            return dict(x=E(nl + 1, M, Dm, **f32), xm=E(nl, M, Dm, **f32), y1=E(nl, M, Dm, **lp), y2=E(nl, M, Dm, **lp),
+            return dict(x=E(nl + 1, M, Dm, **rs), xm=E(nl, M, Dm, **rs), y1=E(nl, M, Dm, **lp), y2=E(nl, M, Dm, **lp),
                         qkv=E(nl, M, 3 * Dm, **lp), o=E(nl, M, Dm, **lp), pre=E(nl, M, 4 * Dm, **lp), h=E(nl, M, 4 * Dm, **lp),
                         st=E(nl, 4, M, **f32), lse=E(nl, M * H, **f32))
         self.enc = stack(c["Ne"], Me, D, c["He"])
         self.dec = stack(c["Nd"], Md, Dd, c["Hd"])
-        self.lat_lp = E(Me, D, **lp) if T != torch.float32 else None
+        self.lat_lp = E(Me, D, **lp) if (T != torch.float32 and eng.res_dtype == torch.float32) else None
+        self.lat32 = E(Me, D, **f32) if eng.res_dtype != torch.float32 else None   # fp32 copy of the latent for the loss heads / outputs
         self.z = E(Me, Dd, **f32)
         self.emb_lp = E(Md, Dd, **lp)
         self.emb32 = E(Md, Dd, **f32)
@@ -182,7 +184,7 @@ class Workspace:
         # buffers that the weight-gradient stream reads are ping-ponged so the main chain never waits for it (see Engine._dw)
         self.dres_e = E(Mmax_e, D, **f32)
         self.dres_e_lp = [E(Mmax_e, D, **lp), E(Mmax_e, D, **lp)]
-        self.dres_d = E(Mmax_d, Dd, **f32)
+        self.dres_d = E(Mmax_d, Dd, **f32) if eng.res_dtype == torch.float32 else None
         self.dres_d_lp = [E(Mmax_d, Dd, **lp), E(Mmax_d, Dd, **lp)]
         big = max(Me * 4 * D, Md * 4 * Dd)
         self.t4 = [E(big, **lp), E(big, **lp)]      # dpre
@@ -192,7 +194,10 @@ class Workspace:
         self.demb = E(Md, Dd, **f32)
         self.dz_lp = E(Me, Dd, **lp)
         self.dtok_lp = E(B2 * max(keep, 1), D, **lp)
-        self.ln_ws = E(1024 * 2 * max(D, Dd), **f32)  # per-block dgamma/dbeta partial rows of LayerNorm backward
+        # per-block dgamma / dbeta partial rows of every LayerNorm backward of the step (one slice each), folded by ONE launch per
+        # block stack at the end instead of one small reduce per LayerNorm on the critical path
+        self.ln_part_e = E(2 * c["Ne"], 1024 * 2 * D, **f32)
+        self.ln_part_d = E(2 * c["Nd"] + 1, 1024 * 2 * Dd, **f32)
         self.dw_ws = E(64 * 1024 * 1024, **f32)  # split-K slabs of the weight-gradient GEMMs (256 MiB)
 
 
@@ -203,6 +208,10 @@ class Engine:
             raise RuntimeError("csmae_hip.Engine needs an MI355X (device 'cuda'): there is no CPU or eager fallback on the product path")
         self.act_dtype = act_dtype
         self.T = BF16 if act_dtype == torch.bfloat16 else F32
+        # Residual stream (x, x_mid and the residual gradient): fp32 in parity mode.  In throughput mode it is bf16 as well: the
+        # residual epilogues, LayerNorm forward / backward and the stack boundaries move half the bytes (they are HBM- / store-bound,
+        # DESIGN §4).  CSMAE_RESID_FP32=1 keeps the fp32 stream under the bf16 GEMMs (what torch autocast does; A/B aid).
+        self.res_dtype = torch.float32 if (self.T == F32 or os.environ.get("CSMAE_RESID_FP32")) else torch.bfloat16
         v = cfg["variant"]
         self.views = 1 if v == "Baseline" else 2
         self.has_pred = v in ("MsLdCd", "MsLdLeCd", "MsLdCeCd")
@@ -223,6 +232,10 @@ class Engine:
         self.side, self.main, self.aux = None, None, None
         self._fwd_streams = []
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
+        sl = flat.slots
+        goff = lambda names: torch.tensor([[sl[n + ".weight"][0], sl[n + ".bias"][0]] for n in names], dtype=torch.long, device=self.device)
+        self._goff_e = goff([f"encoder.{i}.norm{k}" for i in range(cfg["Ne"]) for k in (1, 2)])
+        self._goff_d = goff([f"decoder.{i}.norm{k}" for i in range(cfg["Nd"]) for k in (1, 2)] + ["decoder_norm"])
 
     # ------------------------------------------------------------------ helpers
     def W(self, name):
@@ -321,9 +334,11 @@ class Engine:
         ops.gemm(y2, self.W(pre + "mlp.fc1.weight"), h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st)
         ops.gemm(h, self.W(pre + "mlp.fc2.weight"), x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st)
 
-    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps):
-        """`lps` = the two ping-pong low-precision copies of the residual gradient; on entry and on exit lps[0] is current."""
-        P, G, st, ws = self.flat.P, self.flat.G, self.st, self.ws
+    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, part):
+        """`lps` = the two ping-pong low-precision copies of the residual gradient; on entry and on exit lps[0] is current.  With a
+        bf16 residual stream they ARE the residual gradient (`dres` is None); with the fp32 stream `dres` is updated in place.
+        `part` = partial-row slices of this block's two LayerNorms (norm1, norm2): their dgamma / dbeta are folded later (_ln_flush)."""
+        P, st, ws = self.flat.P, self.st, self.ws
         stt = S["st"][i]
         lse = S["lse"][i][: B2 * H * T]
         self._tog ^= 1
@@ -337,8 +352,10 @@ class Engine:
         self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
         ops.gemm(dpre, self.W(pre + "mlp.fc1.weight"), t1, trans_b=True, st=st)
         self._guard_write(nxt)
-        ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, G(pre + "norm2.weight"), G(pre + "norm2.bias"),
-                          dres_in=dres, dx_lp=nxt, partial_ws=ws.ln_ws, st=st)
+        if dres is None:
+            ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), nxt, None, None, dres_in=cur, partial_ws=part[1], st=st)
+        else:
+            ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, None, None, dres_in=dres, dx_lp=nxt, partial_ws=part[1], st=st)
         self._dw(nxt, S["o"][i], pre + "attn.proj")
         ops.gemm(nxt, self.W(pre + "attn.proj.weight"), t1, trans_b=True, st=st)
         self._guard_write(dqkv)
@@ -346,8 +363,15 @@ class Engine:
         self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
         ops.gemm(dqkv, self.W(pre + "attn.qkv.weight"), t1, trans_b=True, st=st)
         self._guard_write(cur)
-        ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, G(pre + "norm1.weight"), G(pre + "norm1.bias"),
-                          dres_in=dres, dx_lp=cur, partial_ws=ws.ln_ws, st=st)
+        if dres is None:
+            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), cur, None, None, dres_in=nxt, partial_ws=part[0], st=st)
+        else:
+            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, None, None, dres_in=dres, dx_lp=cur, partial_ws=part[0], st=st)
+
+    def _ln_flush(self, part, goff, lo, hi, M, Dm):
+        """dgamma / dbeta of LayerNorms [lo, hi) of a stack (rows of `part` / `goff`): one deterministic launch."""
+        if hi > lo:
+            ops.ln_param_reduce(hi - lo, M, Dm, part[lo:hi], goff[lo:hi], self.flat.g, st=self.st)
 
     # ------------------------------------------------------------------ forward
     def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool):
@@ -375,6 +399,7 @@ class Engine:
         ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
         ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep, st=st)
         latent = ws.enc["x"][c["Ne"]]
+        lat_heads = ws.lat32 if ws.lat32 is not None else latent   # what the loss heads read (fp32)
         main = torch.cuda.current_stream()
         two = self.views == 2 and ops._timer is None and not os.environ.get("CSMAE_FWD_ONE_STREAM")
         if self.side is None:
@@ -391,17 +416,20 @@ class Engine:
             for i in range(c["Ne"]):
                 self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, b0, nb, st)
                 yield
+            re_, rd_ = slice(b0 * Te, (b0 + nb) * Te), slice(b0 * Td, (b0 + nb) * Td)
+            if ws.lat32 is not None:        # bf16 residual stream: the latent is a GEMM operand as it is; the heads read an fp32 copy
+                ops.cast_f32(latent[re_], ws.lat32[re_], st=st)
+                lat_op = latent[re_]
+            elif self.T == BF16:
+                ops.cast_bf16(latent[re_], ws.lat_lp[re_], st=st)
+                lat_op = ws.lat_lp[re_]
+            else:
+                lat_op = latent[re_]
             ev = None
             if self.has_ce and ops._timer is None:
                 ev = torch.cuda.Event()
                 ev.record(stream_obj)
             evs.append(ev)
-            re_, rd_ = slice(b0 * Te, (b0 + nb) * Te), slice(b0 * Td, (b0 + nb) * Td)
-            if self.T == BF16:
-                ops.cast_bf16(latent[re_], ws.lat_lp[re_], st=st)
-                lat_op = ws.lat_lp[re_]
-            else:
-                lat_op = latent[re_]
             ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z[re_], bias=P("decoder_embed.bias"), st=st)
             ops.unshuffle_fwd(ws.z[re_], P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore[b0:b0 + nb],
                               ws.dec["x"][0][rd_], nb, L, keep, st=st)
@@ -438,7 +466,7 @@ class Engine:
                 self.aux.wait_stream(main)  # (workspace reuse: the previous step's backward read E / zc on the main stream)
                 for ev in evs:
                     self.aux.wait_event(ev)
-                ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
+                ops.ntxent_fwd(lat_heads, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
                 ce_done = torch.cuda.Event()
                 ce_done.record(self.aux)
             for so in self._fwd_streams[: nch - 1]:
@@ -450,10 +478,10 @@ class Engine:
             ev0 = evs[0]
             if self.has_ce:
                 if ev0 is None:
-                    ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
+                    ops.ntxent_fwd(lat_heads, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=st)
                 else:
                     self.aux.wait_stream(main)
-                    ops.ntxent_fwd(latent, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
+                    ops.ntxent_fwd(lat_heads, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
                     ce_done = torch.cuda.Event()
                     ce_done.record(self.aux)
         kind, npx = c["loss"], c["norm_pix"]
@@ -483,7 +511,7 @@ class Engine:
             kw.update(cd_partial=ws.cd_partial, cd_scale=self._pair_scale(kcd, N * L, Dd))
         if self.has_le:
             ke = c["loss_e"]
-            ops.pair_loss_fwd(ke, N * Te, D, latent, (N * Te, 0, N * Te), latent, (N * Te, 0, 0), ws.e_partial, st=st)
+            ops.pair_loss_fwd(ke, N * Te, D, lat_heads, (N * Te, 0, N * Te), lat_heads, (N * Te, 0, 0), ws.e_partial, st=st)
             kw.update(e_partial=ws.e_partial, e_scale=self._pair_scale(ke, N * Te, D))
         if self.has_ce:
             if ce_done is not None:
@@ -521,7 +549,11 @@ class Engine:
         ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], N, keep, st=st)
         for i in range(c["Ne"]):
             self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], N, ws.Te)
-        return ws.enc["x"][c["Ne"]].view(N, ws.Te, D).clone(), ws.mask.clone(), ws.ids_restore.clone()
+        lat = ws.enc["x"][c["Ne"]]
+        if ws.lat32 is not None:
+            ops.cast_f32(lat, ws.lat32, st=st)
+            lat = ws.lat32
+        return lat.view(N, ws.Te, D).clone(), ws.mask.clone(), ws.ids_restore.clone()
 
     def decode(self, latent: torch.Tensor, ids_restore: torch.Tensor):
         """`forward_decoder` (MAE_ViT_Baseline.py:268-297): decoder_embed, mask-token fill + unshuffle + pos-embed, decoder blocks,
@@ -538,8 +570,8 @@ class Engine:
         self._refresh_lp()
         lat = latent.reshape(N * Te, D).to(torch.float32).contiguous()
         if self.T == BF16:
-            ops.cast_bf16(lat, ws.lat_lp, st=st)
-            lat_op = ws.lat_lp
+            lat_op = ws.lat_lp if ws.lat_lp is not None else ws.enc["x"][c["Ne"]]
+            ops.cast_bf16(lat, lat_op, st=st)
         else:
             lat_op = lat
         ws.ids_restore.copy_(ids_restore)
@@ -607,19 +639,26 @@ class Engine:
             ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=st)
             ops.rows_scatter_add(ws.dpin, ws.demb, L, Td, N * Td + 1, st=st)
         # decoder
-        ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d,
-                          G("decoder_norm.weight"), G("decoder_norm.bias"), dx_lp=ws.dres_d_lp[0], partial_ws=ws.ln_ws, st=st)
+        lp_stream = self.res_dtype != torch.float32   # bf16 residual-gradient stream: the ping-pong buffers are the stream itself
+        pd, Nd2 = ws.ln_part_d, 2 * c["Nd"]
+        if lp_stream:
+            ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d_lp[0], None, None,
+                              partial_ws=pd[Nd2], st=st)
+        else:
+            ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d, None, None,
+                              dx_lp=ws.dres_d_lp[0], partial_ws=pd[Nd2], st=st)
         for i in reversed(range(c["Nd"])):
-            self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp)
-        ops.unshuffle_bwd(ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
-        lat_op = ws.lat_lp if self.T == BF16 else ws.enc["x"][c["Ne"]]
+            self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp, (pd[2 * i], pd[2 * i + 1]))
+        self._ln_flush(pd, self._goff_d, 0, Nd2 + 1, ws.Md, Dd)
+        ops.unshuffle_bwd(ws.dres_d_lp[0] if lp_stream else ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
+        lat_op = ws.enc["x"][c["Ne"]] if (lp_stream or self.T != BF16) else ws.lat_lp
         self._dw(ws.dz_lp, lat_op, "decoder_embed")
         ops.gemm(ws.dz_lp, self.W("decoder_embed.weight"), ws.dres_e, trans_b=True, st=st)
         dp = getattr(self.module, "_dp", None)
         if dp is not None:
             self._join_side()
             dp.grads_ready(self.flat, "tail")  # decoder + heads are final: their all-reduce overlaps the encoder backward
-        latent = ws.enc["x"][c["Ne"]]
+        latent = ws.lat32 if ws.lat32 is not None else ws.enc["x"][c["Ne"]]
         if self.has_le:
             ke = c["loss_e"]
             ops.pair_loss_bwd(ke, N * Te, D, latent, (N * Te, 0, N * Te), latent, (N * Te, 0, 0), ws.gout, self._pair_scale(ke, N * Te, D),
@@ -629,12 +668,16 @@ class Engine:
             ops.ntxent_bwd(ws.zc, ws.inv_norm, ws.E, ws.neg, ws.gout, ws.dpool, N, st=st)
             dpool = ws.dpool
         ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp[0], B2, Te, st=st)
+        pe, flushed = ws.ln_part_e, c["Ne"]
         for i in reversed(range(c["Ne"])):
-            self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, ws.dres_e, ws.dres_e_lp)
+            self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, None if lp_stream else ws.dres_e, ws.dres_e_lp, (pe[2 * i], pe[2 * i + 1]))
             if dp is not None and dp.wants(("enc", i)):
+                self._ln_flush(pe, self._goff_e, 2 * i, 2 * flushed, ws.Me, D)   # the bucket's LayerNorm gradients must be final before its exchange
+                flushed = i
                 self._join_side()
                 dp.grads_ready(self.flat, ("enc", i))
-        ops.embed_assemble_bwd(ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
+        self._ln_flush(pe, self._goff_e, 0, 2 * flushed, ws.Me, D)
+        ops.embed_assemble_bwd(ws.dres_e_lp[0] if lp_stream else ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
         self._join_side()
         ops.gemm_dw(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), ws.dw_ws, db=G("patch_embed.proj.bias"), st=st)
         if dp is not None:

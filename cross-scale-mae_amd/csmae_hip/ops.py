@@ -70,6 +70,7 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NON
     Kb, N = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
     assert K == Kb and out.shape[0] == M and out.shape[1] == N, (a.shape, b.shape, out.shape, trans_a, trans_b)
     assert a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    assert resid is None or resid.dtype == out.dtype, "the residual epilogue reads its addend in the output's dtype"
     if _timer is not None:
         _timer.begin()
     check(load().csmae_gemm(dt(a), int(trans_a), int(trans_b), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0),
@@ -103,16 +104,25 @@ def attn_bwd(qkv, out, dout, lse, dqkv, B, T, H, hd, st=None):
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, y32=None, eps=1e-6, st=None):
     M, D = x.shape
-    check(load().csmae_layernorm_fwd(dt(y), M, D, _p(x), _p(gamma), _p(beta), eps, _p(y), _p(y32), _p(mean), _p(rstd),
+    check(load().csmae_layernorm_fwd(dt(x), dt(y), M, D, _p(x), _p(gamma), _p(beta), eps, _p(y), _p(y32), _p(mean), _p(rstd),
                                      st if st is not None else stream()), "csmae_layernorm_fwd")
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx_out, dgamma, dbeta, dres_in=None, dx_lp=None, partial_ws=None, st=None):
+    """x, dres_in and dx_out share one dtype (the residual stream's).  dgamma=None with a workspace: the parameter-gradient partial
+    rows stay in `partial_ws` for ln_param_reduce."""
     M, D = x.shape
+    assert dx_out.dtype == x.dtype and (dres_in is None or dres_in.dtype == x.dtype)
     lp = dt(dx_lp) if dx_lp is not None else dt(dy)
-    check(load().csmae_layernorm_bwd(dt(dy), lp, M, D, _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres_in), _p(dx_out), _p(dx_lp),
+    check(load().csmae_layernorm_bwd(dt(dy), dt(x), lp, M, D, _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres_in), _p(dx_out), _p(dx_lp),
                                      _p(dgamma), _p(dbeta), _p(partial_ws), partial_ws.numel() if partial_ws is not None else 0,
                                      st if st is not None else stream()), "csmae_layernorm_bwd")
+
+
+def ln_param_reduce(count, M, D, partials, goff, gbase, st=None):
+    """partials [>= count, slice] fp32 (row k = LayerNorm k's partial rows), goff [count, 2] int64 offsets of dgamma / dbeta in gbase."""
+    check(load().csmae_ln_param_reduce(count, M, D, _p(partials), partials.stride(0), partials.shape[1], _p(gbase), _p(goff),
+                                       st if st is not None else stream()), "csmae_ln_param_reduce")
 
 
 def bnrelu_fwd(u, gamma, beta, r, mean, rstd, N, L, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, training=True, st=None):
@@ -142,22 +152,22 @@ def patch_gather(img0, img1, ids_keep, out, N, C, S, p, keep, st=None):
 
 
 def embed_assemble(tok, pos, cls, ids_keep, x, B2, keep, st=None):
-    check(load().csmae_embed_assemble(B2, keep, x.shape[-1], _p(tok), _p(pos), _p(cls), _p(ids_keep), _p(x), st if st is not None else stream()),
+    check(load().csmae_embed_assemble(dt(x), B2, keep, x.shape[-1], _p(tok), _p(pos), _p(cls), _p(ids_keep), _p(x), st if st is not None else stream()),
           "csmae_embed_assemble")
 
 
 def embed_assemble_bwd(dx, dtok, dcls, B2, keep, st=None):
-    check(load().csmae_embed_assemble_bwd(dt(dtok), B2, keep, dx.shape[-1], _p(dx), _p(dtok), _p(dcls), st if st is not None else stream()),
+    check(load().csmae_embed_assemble_bwd(dt(dx), dt(dtok), B2, keep, dx.shape[-1], _p(dx), _p(dtok), _p(dcls), st if st is not None else stream()),
           "csmae_embed_assemble_bwd")
 
 
 def unshuffle_fwd(z, mask_token, dpos, ids_restore, xd, B2, L, keep, st=None):
-    check(load().csmae_unshuffle_fwd(B2, L, keep, xd.shape[-1], _p(z), _p(mask_token), _p(dpos), _p(ids_restore), _p(xd),
+    check(load().csmae_unshuffle_fwd(dt(xd), B2, L, keep, xd.shape[-1], _p(z), _p(mask_token), _p(dpos), _p(ids_restore), _p(xd),
                                      st if st is not None else stream()), "csmae_unshuffle_fwd")
 
 
 def unshuffle_bwd(dxd, ids_restore, dz, dmask_token, B2, L, keep, st=None):
-    check(load().csmae_unshuffle_bwd(dt(dz), B2, L, keep, dxd.shape[-1], _p(dxd), _p(ids_restore), _p(dz), _p(dmask_token),
+    check(load().csmae_unshuffle_bwd(dt(dxd), dt(dz), B2, L, keep, dxd.shape[-1], _p(dxd), _p(ids_restore), _p(dz), _p(dmask_token),
                                      st if st is not None else stream()), "csmae_unshuffle_bwd")
 
 
@@ -269,6 +279,10 @@ def augment_u8(src, meta, mean, inv_std, dst, st=None):
 
 def cast_bf16(src, dst, st=None):
     check(load().csmae_cast_f32_to_bf16(src.numel(), _p(src), _p(dst), st if st is not None else stream()), "csmae_cast_f32_to_bf16")
+
+
+def cast_f32(src, dst, st=None):
+    check(load().csmae_cast_bf16_to_f32(src.numel(), _p(src), _p(dst), st if st is not None else stream()), "csmae_cast_bf16_to_f32")
 
 
 def colsum(x, out, st=None):

@@ -28,13 +28,13 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 
 #define EPI_NONE 0    // C = acc + bias
 #define EPI_GELU 1    // x = acc + bias ; C = gelu(x) ; aux = gelu'(x)
-#define EPI_RESID 2   // C = acc + bias + resid (resid fp32)
+#define EPI_RESID 2   // C = acc + bias + resid (resid in C's dtype: the fp32 residual stream, or the bf16 one of throughput mode)
 #define EPI_DGELU 3   // C = acc * aux   (aux = gelu'(x) saved by the forward epilogue)
 #define EPI_ATOMIC 4  // C(fp32) += acc   (split-K, atomics)
 #define EPI_SPLIT 5   // C(fp32)[split] = acc  (split-K partial slabs, reduced by dw_reduce_kernel: deterministic, no atomics)
 
 struct GemmArgs {
-  const void* A; const void* B; void* C; const float* bias; void* aux; const float* resid;
+  const void* A; const void* B; void* C; const float* bias; void* aux; const void* resid;   // resid has C's dtype
   long long lda, ldb, ldc, ldaux, ldr;
   int M, N, K;
   int c_dtype, epi, splitk, tiles_m, tiles_n, ktiles, ktiles_per_split;
@@ -55,8 +55,7 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& p, int m, int n, f4_t
     gelu_both4<TC>(x, v, gp);
     st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)m * p.ldaux + n, gp);
   } else if (p.epi == EPI_RESID) {
-    f4_t r = *reinterpret_cast<const f4_t*>(p.resid + (long long)m * p.ldr + n);
-    v += r;
+    v += ld4<TC>(reinterpret_cast<const TC*>(p.resid) + (long long)m * p.ldr + n);
   } else if (p.epi == EPI_DGELU) {
     v *= ld4<TC>(reinterpret_cast<const TC*>(p.aux) + (long long)m * p.ldaux + n);
   }
@@ -144,7 +143,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, void* Cptr, f4_
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
-      if (EPI == EPI_RESID) ld[slot0 + ps] = *reinterpret_cast<const f4_t*>(p.resid + (long long)gm * p.ldr + gnc);
+      if (EPI == EPI_RESID) ld[slot0 + ps] = ld4<TC>(reinterpret_cast<const TC*>(p.resid) + (long long)gm * p.ldr + gnc);
       else ld[slot0 + ps] = ld4<TC>(reinterpret_cast<const TC*>(p.aux) + (long long)gm * p.ldaux + gnc);
     }
   };
@@ -186,8 +185,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, void* Cptr, f4_
 template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR>
 __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
   constexpr int LPR = FN * 16 / 8, RPP = 64 / LPR, NPASS = EROWS / RPP, NPART = WM / EROWS;
-  constexpr bool NEEDS_LOAD = EPI == EPI_DGELU;
-  static_assert(EPI != EPI_RESID, "the residual epilogue writes fp32");
+  constexpr bool NEEDS_LOAD = EPI == EPI_DGELU || EPI == EPI_RESID;
   const int col = (lane % LPR) * 8, rsub = lane / LPR;
   const int gn = nbase + col;
   const bool ok0 = gn < p.N, ok1 = gn + 4 < p.N;   // N % 4 == 0: a lane's 8 columns are valid as two groups of 4
@@ -195,6 +193,8 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   if (p.bias) { if (ok0) b0 = *reinterpret_cast<const f4_t*>(p.bias + gn); if (ok1) b1 = *reinterpret_cast<const f4_t*>(p.bias + gn + 4); }
   bf16_t* C = reinterpret_cast<bf16_t*>(Cptr);
   bf16_t* X = reinterpret_cast<bf16_t*>(p.aux);
+  const bf16_t* LS = EPI == EPI_RESID ? reinterpret_cast<const bf16_t*>(p.resid) : X;   // what the phase loads: bf16 residual stream / gelu'
+  const long long lds_ = EPI == EPI_RESID ? p.ldr : p.ldaux;
   uint4 ld[NEEDS_LOAD ? NPASS : 1];
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
-        const bf16_t* src = X + (long long)gm * p.ldaux + gn;
+        const bf16_t* src = LS + (long long)gm * lds_ + gn;
         ld[ps] = make_uint4(0, 0, 0, 0);
         if (ok1) ld[ps] = *reinterpret_cast<const uint4*>(src);
         else if (ok0) { const uint2 h = *reinterpret_cast<const uint2*>(src); ld[ps].x = h.x; ld[ps].y = h.y; }
@@ -221,10 +221,11 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
       f4_t v0 = *reinterpret_cast<const f4_t*>(src) + b0, v1 = *reinterpret_cast<const f4_t*>(src + 4) + b1;
       f4_t o0 = v0, o1 = v1;
       if (EPI == EPI_GELU) { const f4_t x0 = v0, x1 = v1; gelu_both4<bf16_t>(x0, o0, v0); gelu_both4<bf16_t>(x1, o1, v1); }
-      if (EPI == EPI_DGELU) {
+      if (EPI == EPI_DGELU || EPI == EPI_RESID) {
         const uint4 a = ld[ps];
-        o0 = v0 * f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
-        o1 = v1 * f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
+        const f4_t a0 = f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+        const f4_t a1 = f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
+        if (EPI == EPI_DGELU) { o0 = v0 * a0; o1 = v1 * a1; } else { o0 = v0 + a0; o1 = v1 + a1; }
       }
       if (gm < p.M) {
         if (ok1) {
@@ -713,10 +714,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
 #define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
 #define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
-  const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || p.ldaux % 8 == 0) && ((uintptr_t)p.aux % 16 == 0);  // 16-byte row segments
+  const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
+                                                                                   : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));  // 16-byte row segments
   if (p.c_dtype == CSMAE_BF16) {
-    if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
-    else if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else EPI_CALL8(EPI_NONE); }
+    if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
+    else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
     else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
     else EPI_CALL(bf16_t, EPI_NONE);
   } else {
@@ -786,7 +788,7 @@ extern "C" int csmae_gemm_force_tile(int cfg) { g_force_cfg = cfg; return 0; }
 extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long long K,
                           const void* A, long long lda, const void* B, long long ldb,
                           void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
-                          void* aux, long long ldaux, const float* resid, long long ldr,
+                          void* aux, long long ldaux, const void* resid, long long ldr,
                           int splitk, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0, "csmae_gemm: empty problem M=%lld N=%lld K=%lld", M, N, K);
   CSMAE_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "csmae_gemm: N and ldc must be multiples of 4 (N=%lld ldc=%lld)", N, ldc);

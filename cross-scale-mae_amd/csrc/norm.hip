@@ -4,8 +4,8 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------ LayerNorm forward
-template <typename TO, int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const float* __restrict__ x, const float* __restrict__ gamma,
+template <typename TX, typename TO, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, TO* __restrict__ y, float* __restrict__ y32,
                                                      float* __restrict__ mean, float* __restrict__ rstd) {
   const int lane = threadIdx.x & 63;
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const f
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int c = lane + i * 64;
-    v[i] = c < nv ? *reinterpret_cast<const f4_t*>(x + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+    v[i] = c < nv ? ld4<TX>(x + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
     s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
   }
   const float mu = wave_sum(s) / D;
@@ -43,11 +43,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const f
 
 // ------------------------------------------------------------------------------------------ LayerNorm backward
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ;  dres_out = dres_in + dx ;  dgamma += dy*xhat ; dbeta += dy
-template <typename TDY, typename TLP, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const TDY* __restrict__ dy, const float* __restrict__ x,
+// TX = type of the residual stream: x, and the residual-gradient stream dres_in / dx_out (fp32, or bf16 in throughput mode, where
+// dx_out itself is the next GEMM's operand and dx_lp is null)
+template <typename TDY, typename TX, typename TLP, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, const float* __restrict__ dres_in,
-                                                     float* __restrict__ dx_out, TLP* __restrict__ dx_lp,
+                                                     const float* __restrict__ gamma, const TX* __restrict__ dres_in,
+                                                     TX* __restrict__ dx_out, TLP* __restrict__ dx_lp,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part) {
   __shared__ float red[4 * 64 * 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -68,14 +70,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = lane + i * 64;
-      dr[i] = (dres_in && c < nv) ? *reinterpret_cast<const f4_t*>(dres_in + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+      dr[i] = (dres_in && c < nv) ? ld4<TX>(dres_in + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = lane + i * 64;
       if (c < nv) {
         f4_t d = ld4<TDY>(dy + row * D + c * 4);
-        xh[i] = (*reinterpret_cast<const f4_t*>(x + row * D + c * 4) - mu) * rs;
+        xh[i] = (ld4<TX>(x + row * D + c * 4) - mu) * rs;
         ag[i] += d * xh[i]; ab[i] += d;
         g[i] = d * gm[i];
         s1 += g[i][0] + g[i][1] + g[i][2] + g[i][3];
@@ -89,13 +91,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
       int c = lane + i * 64;
       if (c < nv) {
         f4_t dx = (g[i] - s1 - xh[i] * s2) * rs + dr[i];
-        *reinterpret_cast<f4_t*>(dx_out + row * D + c * 4) = dx;
+        st4<TX>(dx_out + row * D + c * 4, dx);
         if (dx_lp) st4<TLP>(dx_lp + row * D + c * 4, dx);
       }
     }
   }
-  if (!dgamma) return;
-  // fold the 4 waves' column partials, then one atomic per column per block
+  if (!dgamma && !part) return;
+  // fold the 4 waves' column partials into this block's partial row (or, without a workspace, one atomic per column per block)
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int c = lane + i * 64;
@@ -120,68 +122,106 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
   }
 }
 
-// dgamma/dbeta: per-block partial rows -> one column sum per thread (same-address L2 atomics from 1024 blocks serialise:
-// they cost 3x the kernel's HBM time in the first version)
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(int nblk, int D, const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// dgamma/dbeta: per-block partial rows -> column sums.  One workgroup owns 64 columns of one LayerNorm and adds its sum to the gradient
+// in a fixed order (no atomics: the result is bit-reproducible).  blockIdx.y walks a batch of LayerNorms whose partial rows lie
+// `stride` floats apart and whose dgamma / dbeta sit at goff[2k], goff[2k+1] floats behind `gbase` (the flat gradient buffer), so the
+// whole backward pass needs one launch per block stack instead of one per LayerNorm on its critical path.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(int nblk, int D, const float* __restrict__ part, long long stride,
+                                                              float* __restrict__ gbase, const long long* __restrict__ goff,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
+  const int k = blockIdx.y;
+  part += (long long)k * stride;
+  if (goff) { dgamma = gbase + goff[2 * k]; dbeta = gbase + goff[2 * k + 1]; }
   float s = 0.f;
   if (c < 2 * D)
-    for (int b = blockIdx.y * 4 + ty; b < nblk; b += gridDim.y * 4) s += part[(long long)b * 2 * D + c];
+    for (int b = ty; b < nblk; b += 4) s += part[(long long)b * 2 * D + c];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && c < 2 * D) {
-    s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-    unsafeAtomicAdd(c < D ? dgamma + c : dbeta + (c - D), s);  // gridDim.y-way contention only
+    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float* dst = c < D ? dgamma + c : dbeta + (c - D);
+    *dst += s;
   }
 }
 
-template <typename TO>
-static int ln_fwd_launch(long long M, int D, const float* x, const float* g, const float* b, float eps, void* y, float* y32, float* mean, float* rstd, hipStream_t st) {
+template <typename TX, typename TO>
+static int ln_fwd_launch(long long M, int D, const void* x, const float* g, const float* b, float eps, void* y, float* y32, float* mean, float* rstd, hipStream_t st) {
   dim3 grid(cdiv(M, 4)), block(256);
   int nv = cdiv(D, 256);
-#define LNF(NVV) hipLaunchKernelGGL((ln_fwd_kernel<TO, NVV>), grid, block, 0, st, M, D, x, g, b, eps, (TO*)y, y32, mean, rstd)
+#define LNF(NVV) hipLaunchKernelGGL((ln_fwd_kernel<TX, TO, NVV>), grid, block, 0, st, M, D, (const TX*)x, g, b, eps, (TO*)y, y32, mean, rstd)
   switch (nv) { case 1: LNF(1); break; case 2: LNF(2); break; case 3: LNF(3); break; case 4: LNF(4); break; case 5: LNF(5); break; default: LNF(8); }
 #undef LNF
   return CSMAE_OK;
 }
 
-extern "C" int csmae_layernorm_fwd(int out_dtype, long long M, int D, const float* x, const float* gamma, const float* beta, float eps,
+extern "C" int csmae_layernorm_fwd(int x_dtype, int out_dtype, long long M, int D, const void* x, const float* gamma, const float* beta, float eps,
                                    void* y, float* y32, float* mean, float* rstd, void* stream) {
   CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_fwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
-  if (out_dtype == CSMAE_BF16) ln_fwd_launch<bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, (hipStream_t)stream);
-  else if (out_dtype == CSMAE_F32) ln_fwd_launch<float>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, (hipStream_t)stream);
-  else { csmae_set_error("csmae_layernorm_fwd: bad dtype %d", out_dtype); return CSMAE_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == CSMAE_F32 && out_dtype == CSMAE_BF16) ln_fwd_launch<float, bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, st);
+  else if (x_dtype == CSMAE_F32 && out_dtype == CSMAE_F32) ln_fwd_launch<float, float>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, st);
+  else if (x_dtype == CSMAE_BF16 && out_dtype == CSMAE_BF16) ln_fwd_launch<bf16_t, bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, st);
+  else { csmae_set_error("csmae_layernorm_fwd: bad dtypes %d -> %d", x_dtype, out_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_layernorm_fwd");
 }
 
-template <typename TDY, typename TLP>
-static void ln_bwd_launch(long long M, int D, const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                          const float* dres_in, float* dx_out, void* dx_lp, float* dgamma, float* dbeta, float* part, long long part_elems,
-                          hipStream_t st) {
+// partial rows a launch leaves in its workspace (the caller of the deferred reduce needs the same number)
+static int ln_bwd_blocks(long long M, int D, long long part_elems) {
   int blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
-  if (part && part_elems / (2 * D) < blocks) blocks = (int)(part_elems / (2 * D));
-  if (blocks < 1 || !dgamma) part = nullptr, blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
-  dim3 grid(blocks), block(256);
-  int nv = cdiv(D, 256);
-#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, x, mean, rstd, gamma, dres_in, dx_out, (TLP*)dx_lp, dgamma, dbeta, part)
-  switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break; case 5: LNB(5); break; default: LNB(8); }
-#undef LNB
-  if (part) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), 16), dim3(256), 0, st, blocks, D, part, dgamma, dbeta);
+  if (part_elems / (2 * D) < blocks) blocks = (int)(part_elems / (2 * D));
+  return blocks;
 }
 
-extern "C" int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int D, const void* dy, const float* x, const float* mean,
-                                   const float* rstd, const float* gamma, const float* dres_in, float* dx_out, void* dx_lp,
+template <typename TDY, typename TX, typename TLP>
+static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                          const void* dres_in, void* dx_out, void* dx_lp, float* dgamma, float* dbeta, float* part, long long part_elems,
+                          hipStream_t st) {
+  int blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
+  if (part) {
+    blocks = ln_bwd_blocks(M, D, part_elems);
+    if (blocks < 1) part = nullptr, blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
+  }
+  dim3 grid(blocks), block(256);
+  int nv = cdiv(D, 256);
+#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, (const TX*)dres_in, (TX*)dx_out, (TLP*)dx_lp, dgamma, dbeta, part)
+  switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break; case 5: LNB(5); break; default: LNB(8); }
+#undef LNB
+  if (part && dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), 1), dim3(256), 0, st, blocks, D, part, 0ll, (float*)nullptr, (const long long*)nullptr, dgamma, dbeta);
+}
+
+extern "C" int csmae_layernorm_bwd(int dy_dtype, int x_dtype, int lp_dtype, long long M, int D, const void* dy, const void* x, const float* mean,
+                                   const float* rstd, const float* gamma, const void* dres_in, void* dx_out, void* dx_lp,
                                    float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* stream) {
   CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  CSMAE_REQUIRE(dgamma || !partial_ws || partial_elems >= 2ll * D, "csmae_layernorm_bwd: deferred parameter gradients need a workspace of at least one partial row");
   hipStream_t st = (hipStream_t)stream;
-  if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_BF16) ln_bwd_launch<bf16_t, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
-  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_BF16) ln_bwd_launch<float, bf16_t>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
-  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_F32) ln_bwd_launch<float, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
-  else if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_F32) ln_bwd_launch<bf16_t, float>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st);
+#define GO(A, X, L) ln_bwd_launch<A, X, L>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st)
+  if (x_dtype == CSMAE_BF16) {       // bf16 residual streams (throughput mode): dx_out is the GEMM operand itself
+    if (dy_dtype == CSMAE_BF16) GO(bf16_t, bf16_t, bf16_t);
+    else if (dy_dtype == CSMAE_F32) GO(float, bf16_t, bf16_t);
+    else { csmae_set_error("csmae_layernorm_bwd: bad dtypes %d/%d/%d", dy_dtype, x_dtype, lp_dtype); return CSMAE_ERR_UNSUPPORTED; }
+  } else if (x_dtype != CSMAE_F32) { csmae_set_error("csmae_layernorm_bwd: bad x dtype %d", x_dtype); return CSMAE_ERR_UNSUPPORTED; }
+  else if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_BF16) GO(bf16_t, float, bf16_t);
+  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_BF16) GO(float, float, bf16_t);
+  else if (dy_dtype == CSMAE_F32 && lp_dtype == CSMAE_F32) GO(float, float, float);
+  else if (dy_dtype == CSMAE_BF16 && lp_dtype == CSMAE_F32) GO(bf16_t, float, float);
   else { csmae_set_error("csmae_layernorm_bwd: bad dtypes %d/%d", dy_dtype, lp_dtype); return CSMAE_ERR_UNSUPPORTED; }
+#undef GO
   return csmae_check_launch("csmae_layernorm_bwd");
+}
+
+// Deferred dgamma / dbeta of a batch of LayerNorm backward launches that were called with dgamma == NULL and their own workspace
+// slice: LayerNorm k's partial rows start at partials + k * stride (M, D and the slice size must be those of the launches).
+extern "C" int csmae_ln_param_reduce(int count, long long M, int D, const float* partials, long long stride, long long slice_elems,
+                                     float* gbase, const long long* goff, void* stream) {
+  CSMAE_REQUIRE(count > 0 && M > 0 && D > 0 && partials && gbase && goff && slice_elems >= 2ll * D, "csmae_ln_param_reduce: bad arguments");
+  const int blocks = ln_bwd_blocks(M, D, slice_elems);
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), count), dim3(256), 0, (hipStream_t)stream, blocks, D, partials, stride, gbase, goff,
+                     (float*)nullptr, (float*)nullptr);
+  return csmae_check_launch("csmae_ln_param_reduce");
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm(token axis)+ReLU

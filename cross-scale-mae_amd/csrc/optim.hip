@@ -129,6 +129,18 @@ extern "C" int csmae_cast_f32_to_bf16(long long n, const float* src, void* dst, 
   return csmae_check_launch("csmae_cast_f32_to_bf16");
 }
 
+__global__ __launch_bounds__(256) void cast_f32_kernel(long long n, const bf16_t* __restrict__ src, float* __restrict__ dst) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    *reinterpret_cast<f4_t*>(dst + i * 4) = ld4<bf16_t>(src + i * 4);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = bf2f(src[n4 * 4 + threadIdx.x]);
+}
+extern "C" int csmae_cast_bf16_to_f32(long long n, const void* src, float* dst, void* stream) {
+  CSMAE_REQUIRE(n > 0 && src && dst && (((uintptr_t)src & 7) == 0) && (((uintptr_t)dst & 15) == 0), "csmae_cast_bf16_to_f32: bad args");
+  hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)fmin((double)cdiv(n, 1024), 4096.0)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)src, dst);
+  return csmae_check_launch("csmae_cast_bf16_to_f32");
+}
+
 // out[n] += sum_m x[m, n].  block = 64 column-quads x 4 row lanes... 256 threads: tx = column quad (0..63), ty = row lane (0..3)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(long long M, int N, const T* __restrict__ x, long long ld, float* __restrict__ out) {

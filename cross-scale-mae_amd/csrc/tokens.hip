@@ -153,28 +153,32 @@ extern "C" int csmae_patch_gather(int dtype, long long rows, int keep, int N, in
 }
 
 // ------------------------------------------------------------------------------------------ pos-embed add + cls prepend
+template <typename TX>   // TX: type of the residual stream (fp32; bf16 in throughput mode)
 __global__ __launch_bounds__(256) void embed_assemble_kernel(int keep, int D, const float* __restrict__ tok, const float* __restrict__ pos,
-                                                             const float* __restrict__ cls, const int* __restrict__ ids_keep, float* __restrict__ x) {
+                                                             const float* __restrict__ cls, const int* __restrict__ ids_keep, TX* __restrict__ x) {
   const long long n2 = blockIdx.x;
   const int t = blockIdx.y;  // 0 = cls
   const int dv = D >> 2;
-  float* dst = x + (n2 * (keep + 1) + t) * D;
+  TX* dst = x + (n2 * (keep + 1) + t) * D;
   if (t == 0) {
-    for (int c = threadIdx.x; c < dv; c += blockDim.x) *reinterpret_cast<f4_t*>(dst + c * 4) = *reinterpret_cast<const f4_t*>(cls + c * 4) + *reinterpret_cast<const f4_t*>(pos + c * 4);
+    for (int c = threadIdx.x; c < dv; c += blockDim.x) st4<TX>(dst + c * 4, *reinterpret_cast<const f4_t*>(cls + c * 4) + *reinterpret_cast<const f4_t*>(pos + c * 4));
   } else {
     const long long r = n2 * keep + t - 1;
     const float* pp = pos + (long long)(1 + ids_keep[r]) * D;
-    for (int c = threadIdx.x; c < dv; c += blockDim.x) *reinterpret_cast<f4_t*>(dst + c * 4) = *reinterpret_cast<const f4_t*>(tok + r * D + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4);
+    for (int c = threadIdx.x; c < dv; c += blockDim.x) st4<TX>(dst + c * 4, *reinterpret_cast<const f4_t*>(tok + r * D + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4));
   }
 }
-extern "C" int csmae_embed_assemble(long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep, float* x, void* stream) {
+extern "C" int csmae_embed_assemble(int x_dtype, long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep, void* x, void* stream) {
   CSMAE_REQUIRE(B2 > 0 && keep >= 0 && D % 4 == 0, "csmae_embed_assemble: bad geometry");
-  hipLaunchKernelGGL(embed_assemble_kernel, dim3((unsigned)B2, keep + 1), dim3(D >= 1024 ? 256 : 128), 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, x);
+  const dim3 grid((unsigned)B2, keep + 1), block(D >= 1024 ? 256 : 128);
+  if (x_dtype == CSMAE_F32) hipLaunchKernelGGL(embed_assemble_kernel<float>, grid, block, 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, (float*)x);
+  else if (x_dtype == CSMAE_BF16) hipLaunchKernelGGL(embed_assemble_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, (bf16_t*)x);
+  else { csmae_set_error("csmae_embed_assemble: bad dtype %d", x_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_embed_assemble");
 }
 // backward: dtok[n2*keep + t] = dx[n2, 1+t] (cast) ; dcls += sum_n2 dx[n2, 0]
-template <typename T>
-__global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(long long B2, int keep, int D, const float* __restrict__ dx, T* __restrict__ dtok, float* __restrict__ dcls) {
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(long long B2, int keep, int D, const TX* __restrict__ dx, T* __restrict__ dtok, float* __restrict__ dcls) {
   const int dv = D >> 2;
   if (blockIdx.y == 0) {  // cls column sums, deterministic: workgroup b owns columns [4b, 4b + 4) (float4 units); its 128 threads are
     // 4 columns x 32 sample groups, folded through LDS in a fixed order (a serial walk over all 2N samples by D/4 threads of one
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(long long B2, i
     for (int c0 = blockIdx.x * 4; c0 < dv; c0 += gridDim.x * 4) {
       const int c = c0 + cg;
       f4_t s = {0.f, 0.f, 0.f, 0.f};
-      if (c < dv) for (long long n = sg; n < B2; n += 32) s += *reinterpret_cast<const f4_t*>(dx + n * (keep + 1) * D + c * 4);
+      if (c < dv) for (long long n = sg; n < B2; n += 32) s += ld4<TX>(dx + n * (keep + 1) * D + c * 4);
       __syncthreads();
       part[sg][cg] = s;
       __syncthreads();
@@ -199,42 +203,47 @@ __global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(long long B2, i
   const int t = blockIdx.y - 1;
   for (long long n2 = blockIdx.x; n2 < B2; n2 += gridDim.x)
     for (int c = threadIdx.x; c < dv; c += blockDim.x)
-      st4<T>(dtok + (n2 * keep + t) * D + c * 4, *reinterpret_cast<const f4_t*>(dx + (n2 * (keep + 1) + 1 + t) * D + c * 4));
+      st4<T>(dtok + (n2 * keep + t) * D + c * 4, ld4<TX>(dx + (n2 * (keep + 1) + 1 + t) * D + c * 4));
 }
-extern "C" int csmae_embed_assemble_bwd(int dtype, long long B2, int keep, int D, const float* dx, void* dtok, float* dcls, void* stream) {
+extern "C" int csmae_embed_assemble_bwd(int in_dtype, int dtype, long long B2, int keep, int D, const void* dx, void* dtok, float* dcls, void* stream) {
   CSMAE_REQUIRE(B2 > 0 && keep >= 0 && D % 4 == 0, "csmae_embed_assemble_bwd: bad geometry");
   dim3 grid((unsigned)fmin((double)B2, 512.0), keep + 1), block(128);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((embed_assemble_bwd_kernel<bf16_t>), grid, block, 0, st, B2, keep, D, dx, (bf16_t*)dtok, dcls);
-  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((embed_assemble_bwd_kernel<float>), grid, block, 0, st, B2, keep, D, dx, (float*)dtok, dcls);
+  if (in_dtype == CSMAE_BF16 && dtype == CSMAE_BF16) hipLaunchKernelGGL((embed_assemble_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, B2, keep, D, (const bf16_t*)dx, (bf16_t*)dtok, dcls);
+  else if (in_dtype == CSMAE_F32 && dtype == CSMAE_BF16) hipLaunchKernelGGL((embed_assemble_bwd_kernel<float, bf16_t>), grid, block, 0, st, B2, keep, D, (const float*)dx, (bf16_t*)dtok, dcls);
+  else if (in_dtype == CSMAE_F32 && dtype == CSMAE_F32) hipLaunchKernelGGL((embed_assemble_bwd_kernel<float, float>), grid, block, 0, st, B2, keep, D, (const float*)dx, (float*)dtok, dcls);
   else { csmae_set_error("csmae_embed_assemble_bwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_embed_assemble_bwd");
 }
 
 // ------------------------------------------------------------------------------------------ decoder unshuffle
 // xd[n,0] = z[n,0] + dpos[0];  xd[n,1+j] = (r = ids_restore[n,j]) < keep ? z[n,1+r] : mask_token ;  + dpos[1+j]
+template <typename TX>
 __global__ __launch_bounds__(128) void unshuffle_fwd_kernel(int L, int keep, int Dd, const float* __restrict__ z, const float* __restrict__ mask_token,
-                                                            const float* __restrict__ dpos, const long long* __restrict__ ids_restore, float* __restrict__ xd) {
+                                                            const float* __restrict__ dpos, const long long* __restrict__ ids_restore, TX* __restrict__ xd) {
   const long long n = blockIdx.x;
   const int j = blockIdx.y;  // 0 = cls
   const int dv = Dd >> 2;
   const float* src;
   if (j == 0) src = z + n * (keep + 1) * Dd;
   else { long long r = ids_restore[n * L + j - 1]; src = r < keep ? z + (n * (keep + 1) + 1 + r) * Dd : mask_token; }
-  float* dst = xd + (n * (L + 1) + j) * Dd;
+  TX* dst = xd + (n * (L + 1) + j) * Dd;
   const float* pp = dpos + (long long)j * Dd;
   for (int c = threadIdx.x; c < dv; c += blockDim.x)
-    *reinterpret_cast<f4_t*>(dst + c * 4) = *reinterpret_cast<const f4_t*>(src + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4);
+    st4<TX>(dst + c * 4, *reinterpret_cast<const f4_t*>(src + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4));
 }
-extern "C" int csmae_unshuffle_fwd(long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
-                                   const long long* ids_restore, float* xd, void* stream) {
+extern "C" int csmae_unshuffle_fwd(int x_dtype, long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
+                                   const long long* ids_restore, void* xd, void* stream) {
   CSMAE_REQUIRE(B2 > 0 && L > 0 && keep >= 0 && keep <= L && Dd % 4 == 0, "csmae_unshuffle_fwd: bad geometry");
-  hipLaunchKernelGGL(unshuffle_fwd_kernel, dim3((unsigned)B2, L + 1), dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, xd);
+  const dim3 grid((unsigned)B2, L + 1);
+  if (x_dtype == CSMAE_F32) hipLaunchKernelGGL(unshuffle_fwd_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, (float*)xd);
+  else if (x_dtype == CSMAE_BF16) hipLaunchKernelGGL(unshuffle_fwd_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, (bf16_t*)xd);
+  else { csmae_set_error("csmae_unshuffle_fwd: bad dtype %d", x_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_unshuffle_fwd");
 }
 // backward: kept tokens are routed back (unique writers: ids_restore is a permutation), masked positions sum into dmask_token
-template <typename T>
-__global__ __launch_bounds__(512) void unshuffle_bwd_kernel(int L, int keep, int Dd, const float* __restrict__ dxd, const long long* __restrict__ ids_restore,
+template <typename TX, typename T>
+__global__ __launch_bounds__(512) void unshuffle_bwd_kernel(int L, int keep, int Dd, const TX* __restrict__ dxd, const long long* __restrict__ ids_restore,
                                                             T* __restrict__ dz, float* __restrict__ dmask_token) {
   // one workgroup per sample; its threads are (column unit, row group): row group g walks rows j = g, g + RG, ... (a single walk over
   // all L rows by D/4 threads left the kernel latency-bound), the mask-token partials are folded through LDS in a fixed order
@@ -246,10 +255,10 @@ __global__ __launch_bounds__(512) void unshuffle_bwd_kernel(int L, int keep, int
     const int c = c0 + cl;
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
     if (c < dv) {
-      if (g == 0) st4<T>(dz + n * (keep + 1) * Dd + c * 4, *reinterpret_cast<const f4_t*>(dxd + n * (L + 1) * Dd + c * 4));
+      if (g == 0) st4<T>(dz + n * (keep + 1) * Dd + c * 4, ld4<TX>(dxd + n * (L + 1) * Dd + c * 4));
       for (int j = g; j < L; j += RG) {
         long long r = ids_restore[n * L + j];
-        f4_t gr = *reinterpret_cast<const f4_t*>(dxd + (n * (L + 1) + 1 + j) * Dd + c * 4);
+        f4_t gr = ld4<TX>(dxd + (n * (L + 1) + 1 + j) * Dd + c * 4);
         if (r < keep) st4<T>(dz + (n * (keep + 1) + 1 + r) * Dd + c * 4, gr); else acc += gr;
       }
     }
@@ -263,12 +272,13 @@ __global__ __launch_bounds__(512) void unshuffle_bwd_kernel(int L, int keep, int
     }
   }
 }
-extern "C" int csmae_unshuffle_bwd(int dtype, long long B2, int L, int keep, int Dd, const float* dxd, const long long* ids_restore, void* dz,
+extern "C" int csmae_unshuffle_bwd(int in_dtype, int dtype, long long B2, int L, int keep, int Dd, const void* dxd, const long long* ids_restore, void* dz,
                                    float* dmask_token, void* stream) {
   CSMAE_REQUIRE(B2 > 0 && L > 0 && keep >= 0 && keep <= L && Dd % 4 == 0, "csmae_unshuffle_bwd: bad geometry");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((unshuffle_bwd_kernel<bf16_t>), dim3((unsigned)B2), dim3(512), 0, st, L, keep, Dd, dxd, ids_restore, (bf16_t*)dz, dmask_token);
-  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((unshuffle_bwd_kernel<float>), dim3((unsigned)B2), dim3(512), 0, st, L, keep, Dd, dxd, ids_restore, (float*)dz, dmask_token);
+  if (in_dtype == CSMAE_BF16 && dtype == CSMAE_BF16) hipLaunchKernelGGL((unshuffle_bwd_kernel<bf16_t, bf16_t>), dim3((unsigned)B2), dim3(512), 0, st, L, keep, Dd, (const bf16_t*)dxd, ids_restore, (bf16_t*)dz, dmask_token);
+  else if (in_dtype == CSMAE_F32 && dtype == CSMAE_BF16) hipLaunchKernelGGL((unshuffle_bwd_kernel<float, bf16_t>), dim3((unsigned)B2), dim3(512), 0, st, L, keep, Dd, (const float*)dxd, ids_restore, (bf16_t*)dz, dmask_token);
+  else if (in_dtype == CSMAE_F32 && dtype == CSMAE_F32) hipLaunchKernelGGL((unshuffle_bwd_kernel<float, float>), dim3((unsigned)B2), dim3(512), 0, st, L, keep, Dd, (const float*)dxd, ids_restore, (float*)dz, dmask_token);
   else { csmae_set_error("csmae_unshuffle_bwd: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_unshuffle_bwd");
 }

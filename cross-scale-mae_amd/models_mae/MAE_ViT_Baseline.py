@@ -162,7 +162,7 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
     def _outputs(self, eng, ws, N):
         c = eng.cfg
         pred = ws.pred.view(ws.B2, ws.Td, c["P"])
-        lat = ws.enc["x"][c["Ne"]].view(ws.B2, ws.Te, c["D"])
+        lat = (ws.lat32 if ws.lat32 is not None else ws.enc["x"][c["Ne"]]).view(ws.B2, ws.Te, c["D"])   # fp32 (copy of a bf16 stream's latent)
         emb = ws.emb32.view(ws.B2, ws.Td, c["Dd"])
         return (ws.losses[0].clone(), pred[:N, 1:, :], ws.mask[:N], lat[:N], emb[:N])
 

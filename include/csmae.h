@@ -35,11 +35,12 @@ int csmae_abi_version(void);
 /* ---- dense contractions: nn.Linear of timm Block / decoder_embed / decoder_pred / predictor and their backward
  * (timm 0.4.12 Attention.qkv/.proj, Mlp.fc1/.fc2 — call sites models_mae/MAE_ViT_Baseline.py:160-188,270,295;
  *  models_mae/MLP.py:6,9).  C[M,N] = sum_k A(m,k) B(k,n); transX = 0: K contiguous ([M,K] / [N,K]); 1: K strided ([K,M] / [K,N]).
- *  epilogue: NONE (+bias) | GELU (x = acc + bias: C = gelu(x), aux = gelu'(x)) | RESID (C = acc + bias + resid, fp32) |
+ *  epilogue: NONE (+bias) | GELU (x = acc + bias: C = gelu(x), aux = gelu'(x)) | RESID (C = acc + bias + resid; both in c_dtype:
+ *            the fp32 residual stream, or the bf16 one of throughput mode) |
  *            DGELU (C = acc * aux) | ATOMIC (fp32 C += acc) | SPLIT (fp32 split-K slabs, see csmae_gemm_dw). */
 int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long long K,
                const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int c_dtype,
-               const float* bias, int epilogue, void* aux, long long ldaux, const float* resid, long long ldr,
+               const float* bias, int epilogue, void* aux, long long ldaux, const void* resid /* in C's dtype */, long long ldr,
                int splitk, void* stream);
 
 /* weight gradient of nn.Linear: dW[M=out,N=in] (fp32, contiguous) += dY[K,M]^T X[K,N]; token axis split over the chip into fp32 slabs in
@@ -56,14 +57,21 @@ int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, const void* qkv
 int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
                    const float* lse, void* dqkv, void* stream);
 
-/* ---- nn.LayerNorm(eps=1e-6) (MAE_ViT_Baseline.py:43-45): x fp32 [M,D]; y in out_dtype (+ optional fp32 copy y32).
- * bwd: dx_out = dres_in + LN'(dy); dx_lp = low-precision copy for the next GEMM; dgamma/dbeta += via per-block partial rows in
- * partial_ws (>= 2*D floats per block; null -> atomics). */
-int csmae_layernorm_fwd(int out_dtype, long long M, int D, const float* x, const float* gamma, const float* beta, float eps,
+/* ---- nn.LayerNorm(eps=1e-6) (MAE_ViT_Baseline.py:43-45): x [M,D] in x_dtype (the residual stream: fp32, or bf16 in throughput
+ * mode); y in out_dtype (+ optional fp32 copy y32); statistics in fp32.
+ * bwd: dx_out = dres_in + LN'(dy), both in x_dtype (the residual-gradient stream); dx_lp = optional low-precision copy for the next
+ * GEMM (with a bf16 stream dx_out is that operand); dgamma/dbeta += via per-block partial rows in partial_ws (>= 2*D floats per
+ * block; null -> atomics).  dgamma == NULL with a workspace: the partial rows (min(ceil(M/4), 1024, partial_elems / 2D) of them) are
+ * left there for csmae_ln_param_reduce, which folds a whole batch of LayerNorms in one launch off the critical path. */
+int csmae_layernorm_fwd(int x_dtype, int out_dtype, long long M, int D, const void* x, const float* gamma, const float* beta, float eps,
                         void* y, float* y32, float* mean, float* rstd, void* stream);
-int csmae_layernorm_bwd(int dy_dtype, int lp_dtype, long long M, int D, const void* dy, const float* x, const float* mean,
-                        const float* rstd, const float* gamma, const float* dres_in, float* dx_out, void* dx_lp,
+int csmae_layernorm_bwd(int dy_dtype, int x_dtype, int lp_dtype, long long M, int D, const void* dy, const void* x, const float* mean,
+                        const float* rstd, const float* gamma, const void* dres_in, void* dx_out, void* dx_lp,
                         float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* stream);
+/* LayerNorm k of the batch: partial rows at partials + k * stride (slice_elems floats each, written by csmae_layernorm_bwd with the same
+ * M and D), dgamma at gbase + goff[2k], dbeta at gbase + goff[2k+1] (device array).  Fixed summation order, no atomics. */
+int csmae_ln_param_reduce(int count, long long M, int D, const float* partials, long long stride, long long slice_elems,
+                          float* gbase, const long long* goff, void* stream);
 
 /* ---- predictor BatchNorm1d(num_patches) + ReLU (models_mae/MLP.py:7-8): channel = token position, batch statistics
  * over (sample, feature); updates running stats (momentum, unbiased var) and num_batches_tracked in place. */
@@ -82,13 +90,13 @@ int csmae_mask_sort(long long rows, int L, int keep, const float* noise, long lo
 int csmae_patch_gather(int dtype, long long rows, int keep, int N, int C, int S, int p, const float* img0, const float* img1,
                        const int* ids_keep, void* out, long long ld, void* stream);
 /* ---- MAE_ViT_Baseline.py:248,253-256: + encoder_pos_embed, cls prepend (and its backward) */
-int csmae_embed_assemble(long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep,
-                         float* x, void* stream);
-int csmae_embed_assemble_bwd(int dtype, long long B2, int keep, int D, const float* dx, void* dtok, float* dcls, void* stream);
+int csmae_embed_assemble(int x_dtype, long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep,
+                         void* x, void* stream);
+int csmae_embed_assemble_bwd(int in_dtype, int dtype, long long B2, int keep, int D, const void* dx, void* dtok, float* dcls, void* stream);
 /* ---- MAE_ViT_Baseline.forward_decoder (:273-283): mask-token fill, gather(ids_restore), + decoder_pos_embed */
-int csmae_unshuffle_fwd(long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
-                        const long long* ids_restore, float* xd, void* stream);
-int csmae_unshuffle_bwd(int dtype, long long B2, int L, int keep, int Dd, const float* dxd, const long long* ids_restore, void* dz,
+int csmae_unshuffle_fwd(int x_dtype, long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
+                        const long long* ids_restore, void* xd, void* stream);
+int csmae_unshuffle_bwd(int in_dtype, int dtype, long long B2, int L, int keep, int Dd, const void* dxd, const long long* ids_restore, void* dz,
                         float* dmask_token, void* stream);
 /* ---- `[:, 1:, :]` views around the predictor (MAE_ViT_MsLdCeCd.py:57-58) */
 int csmae_rows_gather(int dtype, long long rows, int D, const float* src, long long group, long long gstride, long long off,
@@ -158,6 +166,7 @@ int csmae_gate_accumulate(const float* loss, float* slot, int accumulate, void* 
  * scratch: >= 1024 floats.  No host synchronisation. */
 int csmae_clip_grad_norm(long long n, float* g, float max_norm, float* scratch, float* out, void* stream);
 int csmae_cast_f32_to_bf16(long long n, const float* src, void* dst, void* stream);
+int csmae_cast_bf16_to_f32(long long n, const void* src, float* dst, void* stream);
 int csmae_colsum(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -192,6 +192,100 @@ def test_layernorm(ops, MD, dtype):
     assert_close(db, 2 * br.grad, 1e-4, 2e-3, "ln dbeta (partials)")
 
 
+@pytest.mark.parametrize("MD", [(37, 768), (200, 512), (7, 1280)])
+def test_layernorm_bf16_residual_stream_and_deferred_param_grads(ops, MD):
+    """Throughput mode: the residual stream x and the residual-gradient stream (dres_in -> dx_out) are bf16; statistics and arithmetic
+    stay fp32.  Reference: fp32 torch LayerNorm on the bf16-rounded inputs (exact up to the output rounding).  Parameter gradients of a
+    batch of launches are left as partial rows and folded by ONE csmae_ln_param_reduce launch into a flat gradient buffer at given
+    offsets — deterministically."""
+    M, D = MD
+    x = (rnd(M, D, seed=30, scale=2.0) + 0.5).to(torch.bfloat16)
+    g, b = rnd(D, seed=31) * 0.2 + 1.0, rnd(D, seed=32) * 0.1
+    dy = rnd(M, D, seed=33).to(torch.bfloat16)
+    dres = rnd(M, D, seed=34).to(torch.bfloat16)
+    xr, gr, br = x.float().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    ref.backward(dy.float())
+    y = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), y, mean, rstd)
+    assert_close(y, ref, 1e-2, 1e-2, "ln y (bf16 stream)")
+    assert_close(mean, x.float().mean(1), 1e-5, 1e-5, "ln mean")
+    # three "LayerNorms" of a stack: same launch geometry, own partial slices; the reduce adds into a flat buffer at scattered offsets
+    K = 3
+    part = torch.full((K, 1024 * 2 * D), float("nan"), device="cuda")   # (only the rows a launch writes may be read)
+    outs = []
+    for k in range(K):
+        dx = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        ops.layernorm_bwd(dev(dy) if k != 1 else dev(dy * 2), dev(x), mean, rstd, dev(g), dx, None, None, dres_in=dev(dres), partial_ws=part[k])
+        outs.append(dx)
+    assert_close(outs[0], xr.grad + dres.float(), 1e-2, 2e-2, "ln dx (bf16 stream)")
+    flatg = torch.ones(8 * D + 64, device="cuda")
+    goff = torch.tensor([[0, D], [5 * D + 8, 3 * D], [2 * D, 7 * D + 16]], dtype=torch.long, device="cuda")
+    ops.ln_param_reduce(K, M, D, part, goff, flatg)
+    for k, scale in enumerate((1.0, 2.0, 1.0)):
+        assert_close(flatg[goff[k, 0]: goff[k, 0] + D] - 1.0, scale * gr.grad, 1e-4, 2e-3, f"deferred dgamma {k}")
+        assert_close(flatg[goff[k, 1]: goff[k, 1] + D] - 1.0, scale * br.grad, 1e-4, 2e-3, f"deferred dbeta {k}")
+    again = torch.ones_like(flatg)
+    ops.ln_param_reduce(K, M, D, part, goff, again)
+    assert torch.equal(again, flatg)                                          # fixed summation order
+    touched = torch.zeros_like(flatg, dtype=torch.bool)
+    for k in range(K):
+        touched[goff[k, 0]: goff[k, 0] + D] = True
+        touched[goff[k, 1]: goff[k, 1] + D] = True
+    assert bool((flatg[~touched] == 1.0).all())
+
+
+def test_gemm_residual_epilogue_bf16_stream(ops):
+    """C = A W^T + bias + resid with the residual stream in bf16 (C and resid share a dtype), on the pipelined-kernel shapes
+    (256-row / 192-row tiles) and a small one; reference in fp32 on the same bf16 operands."""
+    from csmae_hip import EPI_RESID
+    for M, N, K in ((512, 512, 512), (400, 768, 256), (64, 128, 64), (1000, 520, 320)):
+        a = rnd(M, K, seed=50).to(torch.bfloat16)
+        w = (rnd(N, K, seed=51) * 0.05).to(torch.bfloat16)
+        bias = rnd(N, seed=52)
+        resid = rnd(M, N, seed=53).to(torch.bfloat16)
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(dev(a), dev(w), out, bias=dev(bias), epilogue=EPI_RESID, resid=dev(resid))
+        ref = a.float() @ w.float().t() + bias + resid.float()
+        assert_close(out, ref, 1e-2, 2e-2, f"gemm resid bf16 {M}x{N}x{K}")
+        with pytest.raises(AssertionError):
+            ops.gemm(dev(a), dev(w), out, bias=dev(bias), epilogue=EPI_RESID, resid=dev(resid.float()))
+
+
+def test_stack_boundaries_bf16_stream(ops):
+    """embed_assemble / unshuffle_fwd write, embed_assemble_bwd / unshuffle_bwd read the bf16 residual stream; bf16 -> fp32 cast."""
+    B2, keep, D, L = 4, 5, 64, 16
+    tok, pos, cls = rnd(B2 * keep, D, seed=60), rnd(L + 1, D, seed=61), rnd(D, seed=62)
+    ids = torch.stack([torch.randperm(L, generator=torch.Generator().manual_seed(70 + i))[:keep] for i in range(B2)]).int()
+    x32, x16 = torch.empty(B2 * (keep + 1), D, device="cuda"), torch.empty(B2 * (keep + 1), D, device="cuda", dtype=torch.bfloat16)
+    ops.embed_assemble(dev(tok), dev(pos), dev(cls), dev(ids), x32, B2, keep)
+    ops.embed_assemble(dev(tok), dev(pos), dev(cls), dev(ids), x16, B2, keep)
+    assert torch.equal(x16, x32.to(torch.bfloat16))
+    back = torch.empty_like(x32)
+    ops.cast_f32(x16, back)
+    assert torch.equal(back, x16.float())
+    dx = rnd(B2 * (keep + 1), D, seed=63).to(torch.bfloat16)
+    dtok_a, dtok_b = torch.empty(B2 * keep, D, device="cuda", dtype=torch.bfloat16), torch.empty(B2 * keep, D, device="cuda", dtype=torch.bfloat16)
+    dcls_a, dcls_b = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.embed_assemble_bwd(dev(dx), dtok_a, dcls_a, B2, keep)
+    ops.embed_assemble_bwd(dev(dx.float()), dtok_b, dcls_b, B2, keep)
+    assert torch.equal(dtok_a, dtok_b) and torch.equal(dcls_a, dcls_b)
+    z, mt, dpos = rnd(B2 * (keep + 1), D, seed=64), rnd(D, seed=65), rnd(L + 1, D, seed=66)
+    ids_restore = torch.stack([torch.randperm(L, generator=torch.Generator().manual_seed(80 + i)) for i in range(B2)])
+    xd32, xd16 = torch.empty(B2 * (L + 1), D, device="cuda"), torch.empty(B2 * (L + 1), D, device="cuda", dtype=torch.bfloat16)
+    ops.unshuffle_fwd(dev(z), dev(mt), dev(dpos), dev(ids_restore), xd32, B2, L, keep)
+    ops.unshuffle_fwd(dev(z), dev(mt), dev(dpos), dev(ids_restore), xd16, B2, L, keep)
+    assert torch.equal(xd16, xd32.to(torch.bfloat16))
+    dxd = rnd(B2 * (L + 1), D, seed=67).to(torch.bfloat16)
+    dz_a, dz_b = torch.zeros(B2 * (keep + 1), D, device="cuda", dtype=torch.bfloat16), torch.zeros(B2 * (keep + 1), D, device="cuda", dtype=torch.bfloat16)
+    dm_a, dm_b = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    ops.unshuffle_bwd(dev(dxd), dev(ids_restore), dz_a, dm_a, B2, L, keep)
+    ops.unshuffle_bwd(dev(dxd.float()), dev(ids_restore), dz_b, dm_b, B2, L, keep)
+    assert torch.equal(dz_a, dz_b)
+    assert_close(dm_a, dm_b, 1e-5, 1e-5, "mask-token gradient")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_bnrelu_token_axis(ops, dtype):
     N, L, Hp = 6, 9, 64
