@@ -18,12 +18,13 @@ LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4, "none": 5}
 SSIM_KINDS = {"ssim": ("none", 1, 1.0), "ms_ssim": ("none", 5, 1.0), "mse_ssim": ("mse", 1, 0.1), "mse_ms_ssim": ("mse", 5, 0.1)}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsmae_hip.so")
+LIB_PATH = os.environ.get("CSMAE_LIB_PATH") or os.path.join(_HERE, "libcsmae_hip.so")   # (override: A/B builds of tools/)
 
 I, L, P, F = c_int, c_longlong, c_void_p, c_float
 _SIGNATURES = {
     "csmae_gemm": [I, I, I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, I, P],
     "csmae_gemm_dw": [I, L, L, L, P, L, P, L, P, P, P, L, P],
+    "csmae_gemm_dw_group": [I, I, L, P, P, P, P, P, P, P, P, I, P, L, P],
     "csmae_gemm_force_tile": [I],
     "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],

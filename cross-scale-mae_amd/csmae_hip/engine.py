@@ -198,7 +198,7 @@ class Workspace:
         # block stack at the end instead of one small reduce per LayerNorm on the critical path
         self.ln_part_e = E(2 * c["Ne"], 1024 * 2 * D, **f32)
         self.ln_part_d = E(2 * c["Nd"] + 1, 1024 * 2 * Dd, **f32)
-        self.dw_ws = E(64 * 1024 * 1024, **f32)  # split-K slabs of the weight-gradient GEMMs (256 MiB)
+        self.dw_ws = E(64 * 1024 * 1024, **f32)  # K-slice slabs of the weight-gradient launches (256 MiB)
 
 
 class Engine:
@@ -232,6 +232,9 @@ class Engine:
         self.side, self.main, self.aux = None, None, None
         self._fwd_streams = []
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
+        self._dw_cache = {}
+        self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
+        self._dw_pairs = os.environ.get("CSMAE_DW_GROUP", "half") != "none"   # tuning aid: "none" = one launch per product
         sl = flat.slots
         goff = lambda names: torch.tensor([[sl[n + ".weight"][0], sl[n + ".bias"][0]] for n in names], dtype=torch.long, device=self.device)
         self._goff_e = goff([f"encoder.{i}.norm{k}" for i in range(cfg["Ne"]) for k in (1, 2)])
@@ -280,24 +283,36 @@ class Engine:
         return max(1, min(want, kt // 4 if kt >= 8 else 1))
 
     def _dw(self, dy, x, name):
-        """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored).
+        """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored)."""
+        self._dw_group([(dy, x, name)])
 
-        Weight gradients are leaves of the backward graph, so they run on a second HIP stream: their ~250-workgroup kernels and
-        the slab reduce fill the CUs that the main chain's tails, small GEMMs, LayerNorm and attention kernels leave idle."""
-        gw = self.flat.G(name + ".weight")
-        gw2 = gw.view(gw.shape[0], -1)
-        dyv, xv = dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]]
+    def _dw_group(self, items):
+        """Weight gradients of several Linear layers over the same tokens, [(dy, x, name)], in one launch (csmae_gemm_dw_group: the
+        products share the chip, K slices are folded inside the kernel, the result goes straight into the gradient buffer).
+
+        Weight gradients are leaves of the backward graph, so they run on a second HIP stream: their workgroups fill the CUs that the
+        main chain's tails, small GEMMs, LayerNorm and attention kernels leave idle."""
+        key = tuple((n, dy.data_ptr(), x.data_ptr()) for dy, x, n in items)
+        grp = self._dw_cache.get(key)
+        if grp is None:
+            prods = []
+            for dy, x, name in items:
+                gw = self.flat.G(name + ".weight")
+                gw2 = gw.view(gw.shape[0], -1)
+                prods.append((dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]], gw2, self.flat.G(name + ".bias")))
+            grp = self._dw_cache[key] = ops.DwGroup(prods, self.ws.dw_ws)
         if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN"):  # per-kernel HIP-event timing (bench.py) measures on the main stream
-            ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, db=self.flat.G(name + ".bias"), st=self.st)
+            grp.launch(self._dw_slots, st=self.st)
             return
         side = self.side
         ev = self._event()
         ev.record(self.main)
         side.wait_event(ev)
-        ops.gemm_dw(dyv, xv, gw2, self.ws.dw_ws, db=self.flat.G(name + ".bias"), st=side.cuda_stream)
+        grp.launch(self._dw_slots, st=side.cuda_stream)
         done = self._event()
         done.record(side)
-        self._side_reads[dy.data_ptr()] = done
+        for dy, _, _ in items:
+            self._side_reads[dy.data_ptr()] = done
 
     def _guard_write(self, buf):
         """Main stream is about to overwrite `buf`: wait for the weight-gradient kernel that still reads it (if any)."""
@@ -346,21 +361,30 @@ class Engine:
         dqkv = ws.t3[self._tog][: M * 3 * Dm].view(M, 3 * Dm)
         t1 = ws.t1[: M * Dm].view(M, Dm)
         cur, nxt = lps
-        self._dw(cur, S["h"][i], pre + "mlp.fc2")
+        pairs = self._dw_pairs   # the block's four weight gradients go out as two launches: (fc2, fc1) once dpre exists, (proj, qkv) after attention
+        if not pairs:
+            self._dw(cur, S["h"][i], pre + "mlp.fc2")
         self._guard_write(dpre)
         ops.gemm(cur, self.W(pre + "mlp.fc2.weight"), dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st)
-        self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
+        if pairs:
+            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1")])
+        else:
+            self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
         ops.gemm(dpre, self.W(pre + "mlp.fc1.weight"), t1, trans_b=True, st=st)
         self._guard_write(nxt)
         if dres is None:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), nxt, None, None, dres_in=cur, partial_ws=part[1], st=st)
         else:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, None, None, dres_in=dres, dx_lp=nxt, partial_ws=part[1], st=st)
-        self._dw(nxt, S["o"][i], pre + "attn.proj")
+        if not pairs:
+            self._dw(nxt, S["o"][i], pre + "attn.proj")
         ops.gemm(nxt, self.W(pre + "attn.proj.weight"), t1, trans_b=True, st=st)
         self._guard_write(dqkv)
         ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
-        self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
+        if pairs:
+            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")])
+        else:
+            self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
         ops.gemm(dqkv, self.W(pre + "attn.qkv.weight"), t1, trans_b=True, st=st)
         self._guard_write(cur)
         if dres is None:
@@ -382,6 +406,7 @@ class Engine:
             raise ValueError(f"mask_ratio={mask_ratio} keeps no patch (L={c['L']})")
         if self.ws is None or self.ws.N != N or self.ws.keep != keep:
             self.ws = None
+            self._dw_cache.clear()
             self.ws = Workspace(self, N, keep)
         ws, P = self.ws, self.flat.P
         self.st = st = ops.stream()
@@ -679,7 +704,7 @@ class Engine:
         self._ln_flush(pe, self._goff_e, 0, 2 * flushed, ws.Me, D)
         ops.embed_assemble_bwd(ws.dres_e_lp[0] if lp_stream else ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
         self._join_side()
-        ops.gemm_dw(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), ws.dw_ws, db=G("patch_embed.proj.bias"), st=st)
+        ops.DwGroup([(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), G("patch_embed.proj.bias"))], ws.dw_ws).launch(256, st=st)
         if dp is not None:
             dp.grads_ready(self.flat, "stem")
             dp.backward_done(self.flat)

@@ -94,6 +94,36 @@ def gemm_dw(dy, x, dw, workspace, db=None, st=None):
         _timer.end(("gemm_bf16" if dy.dtype == torch.bfloat16 else "gemm_f32") + "_TN", 2.0 * M * N * K)
 
 
+class DwGroup:
+    """Argument block of one grouped weight-gradient launch (csmae_gemm_dw_group): the host arrays of device pointers are built once
+    — the engine's workspace and gradient buffers do not move — and re-used every step."""
+
+    def __init__(self, products, workspace):
+        """products: [(dy [K, >=M], x [K, >=N], dw [M, N] fp32 contiguous, db [M] fp32 or None)] with one K."""
+        n = len(products)
+        self.K = products[0][0].shape[0]
+        self.dtype = dt(products[0][0])
+        self.keep = (products, workspace)
+        for dy, x, dw, db in products:
+            assert dy.shape[0] == self.K and x.shape[0] == self.K and dw.is_contiguous() and dy.dtype == x.dtype and dy.stride(1) == 1 and x.stride(1) == 1
+        VP, LL = ctypes.c_void_p * n, ctypes.c_longlong * n
+        self.n = n
+        self.dY, self.X = VP(*[_p(q[0]) for q in products]), VP(*[_p(q[1]) for q in products])
+        self.dW, self.dB = VP(*[_p(q[2]) for q in products]), VP(*[_p(q[3]) for q in products])
+        self.ldy, self.ldx = LL(*[q[0].stride(0) for q in products]), LL(*[q[1].stride(0) for q in products])
+        self.M, self.N = LL(*[q[2].shape[0] for q in products]), LL(*[q[2].shape[1] for q in products])
+        self.flops = sum(2.0 * q[2].shape[0] * q[2].shape[1] * self.K for q in products)
+        self.ws, self.ws_n = _p(workspace), workspace.numel()
+
+    def launch(self, slots=0, st=None):
+        if _timer is not None:
+            _timer.begin()
+        check(load().csmae_gemm_dw_group(self.dtype, self.n, self.K, self.dY, self.ldy, self.X, self.ldx, self.dW, self.dB, self.M, self.N, slots,
+                                         self.ws, self.ws_n, st if st is not None else stream()), "csmae_gemm_dw_group")
+        if _timer is not None:
+            _timer.end(("gemm_bf16" if self.dtype == BF16 else "gemm_f32") + "_TN", self.flops)
+
+
 def attn_fwd(qkv, out, lse, B, T, H, hd, st=None):
     check(load().csmae_attn_fwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(lse), st if st is not None else stream()), "csmae_attn_fwd")
 

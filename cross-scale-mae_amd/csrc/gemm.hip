@@ -466,8 +466,17 @@ extern "C" int csmae_debug_gemm_ts(unsigned long long* out) { return (int)hipMem
 #else
 #define GTS(i)
 #endif
-template <bool TA, bool TB, int BM = 256>  // BM = 192 (K-contiguous A only): 6 instead of 8 A fragments per wave, for outputs whose 256-row
-__global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  // tiling leaves too many CUs idle (N = 768: 150 -> 201 tiles)
+// main-loop ablations of the pipelined kernel, compile-time only (tools/gemm_ablate.sh builds variant libraries; never in the product build):
+// -DGEMM_ABL=1 no fragment reads | 2 no DMA pieces | 4 no MFMAs | 8 no bias-gradient sums
+#ifndef GEMM_ABL
+#define GEMM_ABL 0
+#endif
+// Grouped weight-gradient launches (csmae_gemm_dw_group): where K slice `split` of tile `slot` parks its fp32 tile ([nsplit][nslots]
+// dense 256 x 256 slabs) and its column-sum partials ([nsplit][nslots][256]) when a tile is cut into several slices.
+struct DwFold { float* slab; float* cs_slab; int nsplit; int slot; int nslots; };
+
+template <bool TA, bool TB, int BM, bool GROUP>
+__device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold fold) {
   static_assert(BM == 256 || (BM == 192 && !TA), "192-row tiles exist for K-contiguous A only");
   constexpr int BN = 256, WM = BM / 2, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
   constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;  // ring slot = 32 KiB; a B image fills it, a 192-row A image uses 24 KiB
@@ -475,15 +484,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   __shared__ __attribute__((aligned(16))) char smem[NUNIT * UNIT];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = lane & 15, g = lane >> 4;
-  const int tiles = p.tiles_m * p.tiles_n;
-  const int wg = xcd_remap(blockIdx.x, tiles * p.splitk);
-  const int split = wg / tiles, tile = wg - split * tiles;
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_begin = split * p.ktiles_per_split;
-  const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles), Kdim = p.K;
-  if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
-  void* Cptr = p.epi == EPI_SPLIT ? static_cast<void*>(reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride) : p.C;
+  const int Kdim = p.K;
+  void* Cptr = (!GROUP && p.epi == EPI_SPLIT) ? static_cast<void*>(reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride) : p.C;
 
   GTS(0);
   const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
@@ -513,11 +516,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   const int dbg = p.force_cfg;  // tuning aid (csmae_gemm_force_tile): 16 = main loop only
   // piece q of this wave's share of the A / B image of K step j (absolute), into ring slot `slot`
   auto dma_a = [&](int slot, int j, int q) {
+    if (GEMM_ABL & 2) return;
     const bool ok = !TA ? ((arow + q * 8 < p.M) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
     const unsigned o = ok ? avo[q & 1] + ((unsigned)j * kstepA + (unsigned)q * aqs) : OOB_OFF;
     lds_dma16(rsA, o, smem + slot * UNIT + (w * PPA + q) * 1024);
   };
   auto dma_b = [&](int slot, int j, int q) {
+    if (GEMM_ABL & 2) return;
     const bool ok = !TB ? ((brow + q * 8 < p.N) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
     const unsigned o = ok ? bvo[q & 1] + ((unsigned)j * kstepB + (unsigned)q * bqs) : OOB_OFF;
     lds_dma16(rsB, o, smem + slot * UNIT + (w * PPU + q) * 1024);
@@ -551,6 +556,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
   auto read_a = [&](int slot, int h, auto ic, s8_t& fa) {
     constexpr int i = decltype(ic)::value;
+    if (GEMM_ABL & 1) return;
     const char* sa = smem + slot * UNIT;
     if (!TA) {  // one address register per (slot, half); the fragment index is the instruction's immediate offset
       const unsigned addr = lds0 + (unsigned)(slot * UNIT) + (unsigned)(ra0 ^ (h << 6));
@@ -562,6 +568,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
     }
   };
   auto read_b = [&](int slot, int h, s8_t (&fb)[FN]) {
+    if (GEMM_ABL & 1) return;
     const char* sb = smem + slot * UNIT;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -598,10 +605,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   const int wq = w % NWN;
   float cs[2] = {0.f, 0.f};
   auto mma_row = [&](int i, const s8_t& fa, const s8_t (&fb)[FN]) {
+    if (!(GEMM_ABL & 4)) {
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa), acc[i][j], 0, 0, 0);
-    if (TA && TB && do_cs && wq == (i >> 1)) {
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa), acc[i][j], 0, 0, 0);
+    }
+    if (TA && TB && !(GEMM_ABL & 8) && do_cs && wq == (i >> 1)) {
       const u4_t d = __builtin_bit_cast(u4_t, fa);
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -695,11 +704,41 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
     for (int e = 0; e < 2; ++e) {
       float v = cs[e];
       v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      cs[e] = v;
       const int m = m0 + wm + (2 * wq + e) * 16 + t;
-      if (g == 0 && m < p.M) p.colsum[(long long)split * p.M + m] = v;
+      if (!GROUP && g == 0 && m < p.M) p.colsum[(long long)split * p.M + m] = v;
     }
   }
   if ((dbg & 16) && acc[0][0][0] != 123456.0f) return;  // tuning aid: main loop only
+  if (GROUP) {
+    // ---- weight-gradient tile of a grouped launch.  One K slice: dW += acc, db += column sums, straight into the gradient buffer.
+    // Several slices: row-major fp32 slab + column-sum partials for dw_group_reduce_kernel.  (Folding the slices inside this kernel —
+    // last arriver per tile behind an agent-scope fence — was built and measured: on this 8-XCD part every release / acquire fence
+    // writes back / invalidates a whole L2, which slowed the concurrent main-stream kernels by 15 %: 24.6 -> 28.4 ms per step.)
+    constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
+    float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
+    if (fold.nsplit > 1) {
+      if (do_cs && g == 0) {
+        float* csm = fold.cs_slab + ((long long)split * fold.nslots + fold.slot) * 256;
+        csm[wm + (2 * wq) * 16 + t] = cs[0];
+        csm[wm + (2 * wq + 1) * 16 + t] = cs[1];
+      }
+      GemmArgs q = p;   // the slab is a dense 256 x 256 tile: local coordinates, no edge clipping (the reduce clips)
+      q.M = 256; q.N = 256; q.ldc = 256; q.bias = nullptr;
+      float* mine = fold.slab + ((long long)split * fold.nslots + fold.slot) * (256 * 256);
+      epilogue_rows<float, EPI_NONE, FM, FN, WM, EROWS, ESTR, LPR, RPP>(q, mine, acc, ew, wm, wn, lane, t, g);
+      return;
+    }
+    if (do_cs && g == 0) {   // (one writer per row: the tn == 0 tile's wave (wm, wq))
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int m = m0 + wm + (2 * wq + e) * 16 + t;
+        if (m < p.M) p.colsum[m] += cs[e];
+      }
+    }
+    epilogue_rows<float, EPI_RESID, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g);   // dW = dW + acc (resid = C)
+    return;
+  }
   if (p.epi == EPI_ATOMIC) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -728,6 +767,81 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
 #undef EPI_CALL
 #undef EPI_CALL8
   GTS(3);
+}
+
+template <bool TA, bool TB, int BM = 256>  // BM = 192 (K-contiguous A only): 6 instead of 8 A fragments per wave, for outputs whose 256-row
+__global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  // tiling leaves too many CUs idle (N = 768: 150 -> 201 tiles)
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int wg = xcd_remap(blockIdx.x, tiles * p.splitk);
+  const int split = wg / tiles, tile = wg - split * tiles;
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int kt_begin = split * p.ktiles_per_split;
+  const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles);
+  if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
+  k64_tile<TA, TB, BM, false>(p, tm, tn, split, kt_begin, kt_end, DwFold{});
+}
+
+// ---- grouped weight gradients: the dW products of a transformer block (qkv, proj, fc1, fc2 — same token axis K) in ONE launch.
+// A product on its own cannot fill the chip without cutting K into 10 .. 60 slices (768 x 768: 9 tiles), each of which pays a 256-KiB
+// fp32 slab store and a share of a separate reduce kernel; together the block's 108 (ViT-B encoder) / 48 (decoder) tiles need no or
+// two slices, the fold happens inside the kernel (DwFold above) and the result is accumulated straight into the fp32 gradient.
+#define DW_GROUP_MAX 8
+struct DwDesc { const void* dY; const void* X; float* dW; float* db; int M, N; long long ldy, ldx; int tiles_n, tile0; };
+struct DwGroupArgs {
+  DwDesc d[DW_GROUP_MAX];
+  int n, K, ktiles, ktiles_per_split, nsplit, total_tiles, force_cfg;
+  float* slab; float* cs_slab;
+};
+__global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
+  // slice-major order: the workgroups of one K slice are neighbours (same XCD after the remap) and walk the same rows of dY / X
+  const int wg = xcd_remap(blockIdx.x, ga.total_tiles * ga.nsplit);
+  const int split = wg / ga.total_tiles, tile_id = wg - split * ga.total_tiles;
+  DwDesc d = ga.d[0];   // (selected by a chain of uniform moves: a dynamic index into the by-value argument would go through scratch memory)
+#pragma unroll
+  for (int i = 1; i < DW_GROUP_MAX; ++i) if (i < ga.n && tile_id >= ga.d[i].tile0) d = ga.d[i];
+  const int tile = tile_id - d.tile0;
+  const int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
+  const int kt_begin = split * ga.ktiles_per_split;
+  const int kt_end = min(kt_begin + ga.ktiles_per_split, ga.ktiles);
+  GemmArgs p;
+  p.A = d.dY; p.B = d.X; p.C = d.dW; p.bias = nullptr; p.aux = nullptr; p.resid = d.dW;
+  p.lda = d.ldy; p.ldb = d.ldx; p.ldc = d.N; p.ldaux = 0; p.ldr = d.N;
+  p.M = d.M; p.N = d.N; p.K = ga.K;
+  p.c_dtype = CSMAE_F32; p.epi = EPI_RESID; p.splitk = ga.nsplit; p.tiles_m = 0; p.tiles_n = d.tiles_n; p.ktiles = ga.ktiles; p.ktiles_per_split = ga.ktiles_per_split;
+  p.a_bytes = (unsigned)((long long)ga.K * d.ldy * 2); p.b_bytes = (unsigned)((long long)ga.K * d.ldx * 2);
+  p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db;
+  k64_tile<true, true, 256, true>(p, tm, tn, split, kt_begin, kt_end, DwFold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles});
+}
+// fold of the K slices of a grouped launch: workgroup (tile, quarter) adds the tile's slabs in slice order and accumulates 64 rows into
+// dW (16-byte accesses along rows); quarter 0 of the tn == 0 tiles does the same for the bias gradient.  Ordered: bit-reproducible.
+__global__ __launch_bounds__(256) void dw_group_reduce_kernel(DwGroupArgs ga) {
+  const int tile_id = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  DwDesc d = ga.d[0];
+#pragma unroll
+  for (int i = 1; i < DW_GROUP_MAX; ++i) if (i < ga.n && tile_id >= ga.d[i].tile0) d = ga.d[i];
+  const int tile = tile_id - d.tile0;
+  const int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int c4 = threadIdx.x & 63, r0 = threadIdx.x >> 6;   // 64 float4 columns x 4 rows per pass
+  const long long sstride = (long long)ga.total_tiles * 256 * 256;
+  const float* base = ga.slab + (long long)tile_id * 256 * 256;
+  const int n = n0 + c4 * 4;
+  for (int r = quarter * 64 + r0; r < quarter * 64 + 64; r += 4) {
+    const int m = m0 + r;
+    if (m >= d.M || n >= d.N) continue;
+    float* dst = d.dW + (long long)m * d.N + n;
+    f4_t a = *reinterpret_cast<f4_t*>(dst);
+    for (int sl = 0; sl < ga.nsplit; ++sl) a += *reinterpret_cast<const f4_t*>(base + sl * sstride + r * 256 + c4 * 4);
+    *reinterpret_cast<f4_t*>(dst) = a;
+  }
+  if (quarter == 0 && tn == 0 && d.db != nullptr) {
+    const int m = m0 + threadIdx.x;
+    if (m < d.M) {
+      float a = d.db[m];
+      for (int sl = 0; sl < ga.nsplit; ++sl) a += ga.cs_slab[((long long)sl * ga.total_tiles + tile_id) * 256 + threadIdx.x];
+      d.db[m] = a;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------ fp32 exact
@@ -890,6 +1004,50 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(long long n4, int S, lon
     }
 }
 extern int csmae_colsum_launch(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream);
+
+extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
+                             float* dW, float* db, float* workspace, long long ws_elems, void* stream);
+// Workspace of a grouped launch: [nsplit][tiles] dense 256 x 256 fp32 slabs, then [nsplit][tiles][256] column-sum partials (only
+// written / read when a tile is cut into more than one K slice).
+extern "C" int csmae_gemm_dw_group(int dtype, int count, long long K, const void* const* dY, const long long* ldy, const void* const* X,
+                                   const long long* ldx, float* const* dW, float* const* db, const long long* M, const long long* N, int slots,
+                                   float* workspace, long long ws_elems, void* stream) {
+  CSMAE_REQUIRE(count > 0 && count <= DW_GROUP_MAX && K > 0 && dY && X && dW && M && N && ldy && ldx && workspace, "csmae_gemm_dw_group: bad arguments (1..%d products)", DW_GROUP_MAX);
+  bool fused = dtype == CSMAE_BF16 && g_force_cfg < 0;
+  for (int i = 0; i < count && fused; ++i) fused = M[i] >= 256 && N[i] >= 256 && N[i] % 4 == 0 && ldy[i] % 8 == 0 && ldx[i] % 8 == 0 && ldy[i] >= (M[i] + 7) / 8 * 8 && ldx[i] >= (N[i] + 7) / 8 * 8 &&
+                                                   K * ldy[i] * 2 < 0xFFFFFFF0ll && K * ldx[i] * 2 < 0xFFFFFFF0ll && ((((uintptr_t)dY[i] | (uintptr_t)X[i] | (uintptr_t)dW[i]) & 15) == 0);
+  if (!fused) {  // exact-fp32 parity mode, small products, odd layouts: one product at a time through the slab path
+    for (int i = 0; i < count; ++i) {
+      int rc = csmae_gemm_dw(dtype, M[i], N[i], K, dY[i], ldy[i], X[i], ldx[i], dW[i], db ? db[i] : nullptr, workspace, ws_elems, stream);
+      if (rc) return rc;
+    }
+    return CSMAE_OK;
+  }
+  DwGroupArgs ga;
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    DwDesc& d = ga.d[i];
+    d.dY = dY[i]; d.X = X[i]; d.dW = dW[i]; d.db = db ? db[i] : nullptr; d.M = (int)M[i]; d.N = (int)N[i]; d.ldy = ldy[i]; d.ldx = ldx[i];
+    d.tiles_n = cdiv(N[i], 256); d.tile0 = tiles;
+    tiles += cdiv(M[i], 256) * d.tiles_n;
+  }
+  for (int i = count; i < DW_GROUP_MAX; ++i) ga.d[i] = ga.d[0];
+  ga.n = count; ga.K = (int)K; ga.total_tiles = tiles; ga.force_cfg = 0;
+  ga.ktiles = cdiv(K, 64);
+  if (slots <= 0) slots = 128;
+  long long S = slots / tiles;                       // K slices per tile: as few as fill `slots` workgroups (the rest of the chip runs the main stream)
+  if (S > ga.ktiles / 8) S = ga.ktiles / 8;          // (a slice is at least 8 K steps)
+  const long long per_slice = (long long)tiles * (256 * 256 + 256);
+  if (S > ws_elems / per_slice) S = ws_elems / per_slice;
+  if (S < 1) S = 1;
+  ga.ktiles_per_split = cdiv(ga.ktiles, S);
+  ga.nsplit = cdiv(ga.ktiles, ga.ktiles_per_split);
+  ga.slab = workspace; ga.cs_slab = workspace + (long long)ga.nsplit * tiles * 256 * 256;
+  CSMAE_REQUIRE(ga.nsplit == 1 || ws_elems >= ga.nsplit * per_slice, "csmae_gemm_dw_group: workspace too small");
+  hipLaunchKernelGGL(gemm_dw_group_kernel, dim3(tiles * ga.nsplit), dim3(512), 0, (hipStream_t)stream, ga);
+  if (ga.nsplit > 1) hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(tiles * 4), dim3(256), 0, (hipStream_t)stream, ga);
+  return csmae_check_launch("csmae_gemm_dw_group");
+}
 extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
                              float* dW, float* db, float* workspace, long long ws_elems, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && workspace && ws_elems >= M * N + M, "csmae_gemm_dw: bad arguments / workspace too small");

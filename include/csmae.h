@@ -48,6 +48,14 @@ int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long
  * inside the same kernel by an all-ones MFMA operand (util/misc.py:314 backward products). */
 int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,
                   float* dW, float* db, float* workspace, long long ws_elems, void* stream);
+/* The weight gradients of several nn.Linear layers that reduce over the same K tokens (a transformer block's qkv / proj / fc1 / fc2:
+ * MAE_ViT_Baseline.py:160-188 backward) in ONE launch: host arrays of `count` (<= 8) device pointers / sizes.  Together the products
+ * fill `slots` workgroups (<= 0: 128) with no or few K slices.  One slice: the tile is accumulated into dW / db directly; several: dense
+ * fp32 slabs + one ordered fold for the whole group (bit-reproducible either way).  workspace: >= tiles * slices * 65 792 floats (less
+ * = fewer slices).  fp32 parity mode and products with M or N < 256 are run one by one through csmae_gemm_dw. */
+int csmae_gemm_dw_group(int dtype, int count, long long K, const void* const* dY, const long long* ldy, const void* const* X,
+                        const long long* ldx, float* const* dW, float* const* db, const long long* M, const long long* N, int slots,
+                        float* workspace, long long ws_elems, void* stream);
 /* tuning hook for tools/gemm_bench.py: force the bf16 block tile (0: 128x128, 1: 256x128, 2: 256x256, -1: heuristic) */
 int csmae_gemm_force_tile(int cfg);
 

@@ -120,6 +120,49 @@ def test_gemm_dw_split_slabs(ops, dtype, mnk):
     assert_close(acc, acc0 + dY.float().t() @ X.float(), 1e-4, 1e-3 * K ** 0.5 / 30, "gemm_dw padded")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("slots", [4, 40, 160])
+def test_gemm_dw_group(ops, dtype, slots):
+    """csmae_gemm_dw_group: the weight gradients of several Linear layers over the same tokens in one launch — tiles of all products
+    share the chip; one K slice accumulates into dW / db directly, several (`slots`) go through slabs and one ordered fold.
+    Shapes: a block's qkv / proj / fc1 / fc2 at a small width incl. ragged edges and a padded operand; fp32 = the per-product fallback."""
+    K = 2000 + 24
+    shapes = [(768, 256), (256, 256), (1024, 264), (300, 1024)]    # (out M, in N)
+    prods, refs = [], []
+    for k, (M, N) in enumerate(shapes):
+        dY, X = rnd(K, M, seed=20 + k).to(dtype), rnd(K, N, seed=30 + k).to(dtype)
+        if k == 3:   # padded dY rows (ld > width), as decoder_pred's gradient has them
+            dYp = torch.zeros(K, M + 4, dtype=dtype); dYp[:, :M] = dY
+            dy_dev = dev(dYp)[:, :M]
+        else:
+            dy_dev = dev(dY)
+        acc0, db0 = rnd(M, N, seed=40 + k), rnd(M, seed=50 + k)
+        prods.append((dy_dev, dev(X), dev(acc0.clone()), dev(db0.clone()) if k != 1 else None))
+        refs.append((acc0 + dY.float().t() @ X.float(), db0 + dY.float().sum(0)))
+    ws = torch.empty(8 << 20, device="cuda")
+    grp = ops.DwGroup(prods, ws)
+    grp.launch(slots)
+    tol = 1e-3 * K ** 0.5 / 30
+    for k, ((_, _, dw, db), (rw, rb)) in enumerate(zip(prods, refs)):
+        assert_close(dw, rw, 1e-4, tol, f"group dW {k} slots {slots}")
+        if db is not None:
+            assert_close(db, rb, 1e-4, tol, f"group db {k} slots {slots}")
+    # a second launch accumulates on top, and the result does not depend on which slice finishes last: two fresh runs are bit-identical
+    outs = []
+    for _ in range(2):
+        fresh = [(dy, x, torch.zeros_like(dw), None if db is None else torch.zeros_like(db)) for dy, x, dw, db in prods]
+        g2 = ops.DwGroup(fresh, ws)
+        g2.launch(slots)
+        g2.launch(slots)
+        outs.append(fresh)
+    for a, b in zip(*outs):
+        assert torch.equal(a[2], b[2])
+        if a[3] is not None:   # (the fp32 parity path sums its bias gradient with atomics: equal up to the order of the additions)
+            assert torch.equal(a[3], b[3]) if dtype == torch.bfloat16 else torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-4)
+    k = 0
+    assert_close(outs[0][k][2], 2 * (refs[k][0] - rnd(*shapes[k], seed=40 + k)), 1e-4, 2 * tol, "accumulating launches")
+
+
 def test_gemm_rejects_bad_args(ops):
     import csmae_hip
     a = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)  # K = 12 not a multiple of 8
