@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cross-scale-mae_amd"))
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5033.2           # dense fp8 MFMA peak (2 x bf16; MI355X_MICROARCH.md) — the roof BASELINE.json configs[4] is priced against
 GFLOP_PER_IMAGE = 118.80           # SURVEY.md §8(d), config 2, fwd + bwd (= 3 x 39.599)
 BATCH_PER_GPU, INPUT, PATCH = 128, 224, 16
 
@@ -51,6 +52,18 @@ def build(device, batch, world, loss="mse", preset="base"):
     opt = FusedAdamW(add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95))
     wrapped = DataParallel(model) if world > 1 else model
     return model, wrapped, opt
+
+
+def csrc_hash():
+    """Content hash of the kernel sources: what a committed PMC profile is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cross-scale-mae_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def log(msg):
@@ -108,6 +121,8 @@ def main():
     ap.add_argument("--loss", type=str, default="mse", help="reconstruction loss (the headline metric is defined with mse; e.g. mse_ssim, ms_ssim for SURVEY §8 f-4)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the "
                     "N > 1 code path with several ranks on one GPU: set CSMAE_BENCH_ONE_GPU=1)")
+    ap.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp8"], help="fp8: the blocks' forward / dX GEMMs on the fp8 MFMA path "
+                    "(BASELINE.json configs[4]; use with --preset huge14).  The headline metric is defined in bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -134,6 +149,8 @@ def main():
     if a.batch is None:
         a.batch = pbatch
     model, wrapped, opt = build(device, a.batch, world, a.loss, a.preset)
+    if a.dtype == "fp8":
+        model.compute_dtype = "fp8"
     torch.manual_seed(0 + rank)  # main_pretrain.py:368
     samples = torch.randn(a.batch, chans, size, size, device=device)
 
@@ -183,31 +200,38 @@ def main():
         log("kernel timing pass done")
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["work"] for v in summ.values())
-        kernel = dict(name="gemm_bf16_k64_kernel (MFMA 16x16x32, all three layouts; serialised on one stream for the HIP-event timing)", launches_per_step=sum(v["launches"] for v in summ.values()),
+        kernel = dict(name="GEMM family: gemm_bf16_k64_kernel + gemm_dw_group_kernel (MFMA 16x16x32 bf16)" + (" + gemm_fp8_kernel (MFMA 16x16x128 f8f6f4)" if a.dtype == "fp8" else "") +
+                      "; serialised on one stream for the HIP-event timing", launches_per_step=sum(v["launches"] for v in summ.values()),
                       ms_per_step=round(tot_ms, 3), tflops=round(tot_fl / tot_ms / 1e9, 1),
                       by_layout={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=round(v["work"] / v["ms"] / 1e9, 1)) for k, v in summ.items()})
-    traffic = None  # HBM bytes per GEMM launch from the committed PMC passes (counters cannot be read from inside this process)
+    # HBM bytes per GEMM launch from the committed PMC passes (counters cannot be read from inside this process).  The profile names the
+    # kernel sources it was taken on; any later edit of csrc/ makes it stale and it is NOT reported (null) until the passes are re-run.
+    traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
-        traffic = {"bytes_per_launch": int(t["gemm_bf16_mb_per_launch"] * 2 ** 20), "step_hbm_gb": t["step_hbm_gb"], "source": t["source"]}
+        if t.get("csrc_sha256") == csrc_hash():
+            traffic = {"bytes_per_launch": int(t["gemm_mb_per_launch"] * 2 ** 20), "step_hbm_gb": t["step_hbm_gb"], "source": t["source"], "csrc_sha256": t["csrc_sha256"][:16]}
+        else:
+            log("profiles/pmc_traffic.json was measured on different kernel sources: roofline.traffic = null (re-run tools/pmc_traffic.py)")
     except (OSError, KeyError, ValueError):
         pass
     if rank == 0:
         ips = a.batch * world * a.steps / elapsed
         ach = ips / world * gflop / 1e3  # TFLOP/s per GPU
-        scale = a.batch == BATCH_PER_GPU and a.loss == "mse" and a.preset == "base"
+        scale = a.batch == BATCH_PER_GPU and a.loss == "mse" and a.preset == "base" and a.dtype == "bf16"
+        peak = PEAK_FP8_TFLOPS if a.dtype == "fp8" else PEAK_BF16_TFLOPS
         out = {
             "metric": "pretrain images/sec ViT-B/16 224^2 two-scale", "value": round(ips, 2), "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{factory} /{patch}, {size}^2 two-scale crops, mask 0.75, AdamW, full optimizer step" if a.preset != "base" else
                        "MAE_ViT_MsLdCeCd ViT-B/16, 224^2 two-scale crops, mask 0.75, AdamW, full optimizer step",
                        "loss": a.loss, "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [chans, size, size], "parallelism": f"dp{world}",
                        "headline_config": bool(scale)},
             "loss": round(final_loss, 5),
-            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic if a.preset == "base" else None, "algorithmic_gflop_per_image": gflop, "dominant_kernel": kernel},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "traffic": traffic if (a.preset == "base" and a.dtype == "bf16" and scale) else None, "algorithmic_gflop_per_image": gflop, "dominant_kernel": kernel},
         }
         if world == 1 and not a.no_cpu_baseline and a.preset == "base":
             out["cpu_baseline"] = cpu_baseline()

@@ -198,12 +198,26 @@ class Workspace:
         # block stack at the end instead of one small reduce per LayerNorm on the critical path
         self.ln_part_e = E(2 * c["Ne"], 1024 * 2 * D, **f32)
         self.ln_part_d = E(2 * c["Nd"] + 1, 1024 * 2 * Dd, **f32)
+        if eng.fp8:   # fp8 staging of the A operand (one buffer per forward stream) and the per-GEMM scale scalars of a step
+            big8 = max(Me * 4 * D, Md * 4 * Dd)
+            self.a8 = [E(big8, device=dev, dtype=torch.uint8) for _ in range(2)]
+            nsite = 8 * (c["Ne"] + c["Nd"]) * 2 + 16
+            self.fp8_amax = [torch.zeros(nsite, **f32), torch.zeros(nsite, **f32)]   # this step's / the previous step's max|x| per GEMM site
+            self.fp8_dq = torch.ones(nsite, **f32)
+            self.fp8_hist = False    # the previous step's amax exist (delayed scaling from the second step on)
+            self.fp8_complete = False
         self.dw_ws = E(64 * 1024 * 1024, **f32)  # K-slice slabs of the weight-gradient launches (256 MiB)
 
 
 class Engine:
     def __init__(self, module: torch.nn.Module, flat: FlatParams, cfg: dict, act_dtype=torch.bfloat16):
         self.module, self.cfg, self.device = module, cfg, flat.p.device
+        # "fp8" (BASELINE.json configs[4]): the bf16 engine with the transformer blocks' forward and dX GEMMs on the fp8 MFMA path
+        # (per-tensor scaled OCP fp8 operands: activations / weights e4m3, gradients e5m2; fp32 accumulation; weight gradients stay bf16)
+        self.fp8 = act_dtype == "fp8"
+        self._fp8_site = 0
+        if self.fp8:
+            act_dtype = torch.bfloat16
         if self.device.type != "cuda":
             raise RuntimeError("csmae_hip.Engine needs an MI355X (device 'cuda'): there is no CPU or eager fallback on the product path")
         self.act_dtype = act_dtype
@@ -275,6 +289,64 @@ class Engine:
             return self.w_pred_pad
         return self.W("decoder_pred.weight")
 
+    # ------------------------------------------------------------------ fp8 path
+    def _fp8_names(self):
+        c = self.cfg
+        return [f"{stk}.{i}.{w}.weight" for stk, n in (("encoder", c["Ne"]), ("decoder", c["Nd"])) for i in range(n)
+                for w in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")]
+
+    def _refresh_fp8(self):
+        """fp8 mirrors of the block weights, re-quantised from the fp32 masters every forward (per-tensor current scaling): W8 [out][in]
+        for the forward products, W8T [in][out] for dX — so that every fp8 GEMM reads two K-contiguous operands."""
+        f = self.flat
+        if getattr(f, "w8", None) is None:
+            f.w8 = torch.zeros(f.total, device=self.device, dtype=torch.uint8)
+            f.w8t = torch.zeros(f.total, device=self.device, dtype=torch.uint8)
+            f.w8_idx = {n: k for k, n in enumerate(self._fp8_names())}
+            f.w8_amax = torch.zeros(len(f.w8_idx), device=self.device)
+            f.w8_dq = torch.ones(len(f.w8_idx), device=self.device)
+        f.w8_amax.zero_()
+        for n, k in f.w8_idx.items():
+            o, cnt, shape = f.slots[n]
+            w = f.p[o:o + cnt].view(shape)
+            ops.fp8_quantize(w, f.w8[o:o + cnt].view(shape), f.w8_amax[k:k + 1], f.w8_dq[k:k + 1])
+            ops.fp8_quantize(w, f.w8t[o:o + cnt].view(shape[1], shape[0]), f.w8_amax[k:k + 1], f.w8_dq[k:k + 1], transpose=True)
+
+    def _fp8_begin(self):
+        """Start of a step in fp8 mode: weight mirrors, site counter, amax pools.  Activations / gradients are scaled with the amax the
+        same GEMM site saw in the previous step (one pass per tensor); the first step of a workspace measures its own (two passes)."""
+        if self.fp8:
+            ws = self.ws
+            self._refresh_fp8()
+            if ws.fp8_complete:            # the last pass through this workspace was a whole forward + backward
+                ws.fp8_amax.reverse()      # what it recorded becomes "previous"
+                ws.fp8_hist = True
+            else:                          # first step, or the last pass was a different one (eval / stand-alone halves): start over
+                ws.fp8_hist = False
+            ws.fp8_complete = False
+            ws.fp8_amax[0].zero_()
+            self._fp8_site = 0
+
+    def _mm(self, a, name, out, *, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None, lane=0):
+        """out = a W^T (forward) / a W (trans_b: dX) for a block weight `name`, through the bf16 / fp32 GEMM or, in fp8 mode, through
+        quantise(a) + the fp8 GEMM.  `lane` picks the fp8 staging buffer (the two forward streams quantise concurrently)."""
+        if not self.fp8:
+            return ops.gemm(a, self.W(name), out, trans_b=trans_b, bias=bias, epilogue=epilogue, aux=aux, resid=resid, st=st)
+        f, ws = self.flat, self.ws
+        M, K = a.shape
+        o, cnt, shape = f.slots[name]
+        b8 = f.w8t[o:o + cnt].view(shape[1], shape[0]) if trans_b else f.w8[o:o + cnt].view(shape)
+        k = self._fp8_site
+        self._fp8_site += 1
+        a8 = ws.a8[lane][: M * K].view(M, K)
+        fmt = ops.FP8_E5M2 if trans_b else ops.FP8_E4M3
+        if ws.fp8_hist:
+            ops.fp8_quantize(a, a8, ws.fp8_amax[1][k:k + 1], ws.fp8_dq[k:k + 1], fmt=fmt, amax_next=ws.fp8_amax[0][k:k + 1], st=st)
+        else:
+            ops.fp8_quantize(a, a8, ws.fp8_amax[0][k:k + 1], ws.fp8_dq[k:k + 1], fmt=fmt, st=st)
+        wi = f.w8_idx[name]
+        return ops.gemm_fp8(a8, b8, out, ws.fp8_dq[k:k + 1], f.w8_dq[wi:wi + 1], a_fmt=fmt, bias=bias, epilogue=epilogue, aux=aux, resid=resid, st=st)
+
     @staticmethod
     def _splitk(m_out, n_out, k_red, tile, ktile):
         tiles = math.ceil(m_out / tile) * math.ceil(n_out / tile)
@@ -342,12 +414,12 @@ class Engine:
         lse = S["lse"][i][b0 * H * T: (b0 + nb) * H * T]
         y1, qkv, o, y2, h, pre_a = S["y1"][i][r], S["qkv"][i][r], S["o"][i][r], S["y2"][i][r], S["h"][i][r], S["pre"][i][r]
         ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], st=st)
-        ops.gemm(y1, self.W(pre + "attn.qkv.weight"), qkv, bias=P(pre + "attn.qkv.bias"), st=st)
+        self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=int(b0 > 0))
         ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, st=st)
-        ops.gemm(o, self.W(pre + "attn.proj.weight"), x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st)
+        self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0))
         ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], st=st)
-        ops.gemm(y2, self.W(pre + "mlp.fc1.weight"), h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st)
-        ops.gemm(h, self.W(pre + "mlp.fc2.weight"), x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st)
+        self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=int(b0 > 0))
+        self._mm(h, pre + "mlp.fc2.weight", x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st, lane=int(b0 > 0))
 
     def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, part):
         """`lps` = the two ping-pong low-precision copies of the residual gradient; on entry and on exit lps[0] is current.  With a
@@ -365,12 +437,12 @@ class Engine:
         if not pairs:
             self._dw(cur, S["h"][i], pre + "mlp.fc2")
         self._guard_write(dpre)
-        ops.gemm(cur, self.W(pre + "mlp.fc2.weight"), dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st)
+        self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st)
         if pairs:
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1")])
         else:
             self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
-        ops.gemm(dpre, self.W(pre + "mlp.fc1.weight"), t1, trans_b=True, st=st)
+        self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st)
         self._guard_write(nxt)
         if dres is None:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), nxt, None, None, dres_in=cur, partial_ws=part[1], st=st)
@@ -378,14 +450,14 @@ class Engine:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, None, None, dres_in=dres, dx_lp=nxt, partial_ws=part[1], st=st)
         if not pairs:
             self._dw(nxt, S["o"][i], pre + "attn.proj")
-        ops.gemm(nxt, self.W(pre + "attn.proj.weight"), t1, trans_b=True, st=st)
+        self._mm(nxt, pre + "attn.proj.weight", t1, trans_b=True, st=st)
         self._guard_write(dqkv)
         ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
         if pairs:
             self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")])
         else:
             self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
-        ops.gemm(dqkv, self.W(pre + "attn.qkv.weight"), t1, trans_b=True, st=st)
+        self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st)
         self._guard_write(cur)
         if dres is None:
             ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), cur, None, None, dres_in=nxt, partial_ws=part[0], st=st)
@@ -412,6 +484,7 @@ class Engine:
         self.st = st = ops.stream()
         B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
         self._refresh_lp()
+        self._fp8_begin()
         img0 = imgs
         img1 = None
         if self.views == 2:
@@ -567,6 +640,7 @@ class Engine:
         self.st = st = ops.stream()
         L, D = c["L"], c["D"]
         self._refresh_lp()
+        self._fp8_begin()
         ws.noise.copy_(noise)
         ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
         ops.patch_gather(imgs, None, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
@@ -593,6 +667,7 @@ class Engine:
         ws, P = self.ws, self.flat.P
         self.st = st = ops.stream()
         self._refresh_lp()
+        self._fp8_begin()
         lat = latent.reshape(N * Te, D).to(torch.float32).contiguous()
         if self.T == BF16:
             lat_op = ws.lat_lp if ws.lat_lp is not None else ws.enc["x"][c["Ne"]]
@@ -708,6 +783,8 @@ class Engine:
         if dp is not None:
             dp.grads_ready(self.flat, "stem")
             dp.backward_done(self.flat)
+        if self.fp8:
+            ws.fp8_complete = True
         # hand the gradient views to autograd's .grad slots (frozen and unused parameters keep None — encoder_norm: E1)
         for name, p in self.flat.params.items():
             if p.requires_grad and not name.startswith("encoder_norm."):

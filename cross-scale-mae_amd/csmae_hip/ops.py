@@ -94,6 +94,40 @@ def gemm_dw(dy, x, dw, workspace, db=None, st=None):
         _timer.end(("gemm_bf16" if dy.dtype == torch.bfloat16 else "gemm_f32") + "_TN", 2.0 * M * N * K)
 
 
+# ---- fp8 MFMA path (BASELINE.json configs[4])
+FP8_E4M3, FP8_E5M2 = 0, 1
+
+
+def fp8_quantize(src, dst, amax, dq, fmt=FP8_E4M3, transpose=False, amax_next=None, st=None):
+    """dst (uint8: OCP fp8 bytes) = fp8(src * FMAX / amax), per-tensor scale on the device, `dq` receives the de-quantisation factor.
+    Current scaling (amax_next None): `amax` (1-element fp32, zeroed by the caller) first receives max|src|.  Delayed scaling: `amax` is
+    the previous step's value and is only read; this step's max|src| is folded into `amax_next` (zeroed by the caller).
+    transpose: dst is [cols, rows] (weight mirror for dX)."""
+    rows, cols = src.shape
+    assert dst.dtype == torch.uint8 and dst.shape == ((cols, rows) if transpose else (rows, cols)) and src.stride(1) == 1 and dst.stride(1) == 1
+    s = st if st is not None else stream()
+    if amax_next is None:
+        check(load().csmae_fp8_amax(dt(src), rows, cols, _p(src), src.stride(0), _p(amax), s), "csmae_fp8_amax")
+    check(load().csmae_fp8_quantize(dt(src), fmt, int(transpose), rows, cols, _p(src), src.stride(0), _p(dst), dst.stride(0), _p(amax), _p(dq),
+                                    _p(amax_next), s), "csmae_fp8_quantize")
+
+
+def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None):
+    """out[M,N] = dq_a * dq_b * a8[M,K] b8[N,K]^T (+ epilogue): both operands K-contiguous fp8 bytes (uint8 tensors)."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == K and out.shape == (M, N)
+    assert resid is None or resid.dtype == out.dtype
+    if _timer is not None:
+        _timer.begin()
+    check(load().csmae_gemm_fp8(a_fmt, M, N, K, _p(a8), a8.stride(0), _p(b8), b8.stride(0), _p(out), out.stride(0), dt(out), _p(bias), epilogue,
+                                _p(aux), aux.stride(0) if aux is not None else 0, _p(resid), resid.stride(0) if resid is not None else 0,
+                                _p(dq_a), _p(dq_b), st if st is not None else stream()), "csmae_gemm_fp8")
+    if _timer is not None:
+        _timer.end("gemm_fp8_NT", 2.0 * M * N * K)
+    return out
+
+
 class DwGroup:
     """Argument block of one grouped weight-gradient launch (csmae_gemm_dw_group): the host arrays of device pointers are built once
     — the engine's workspace and gradient buffers do not move — and re-used every step."""

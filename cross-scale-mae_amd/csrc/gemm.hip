@@ -42,6 +42,8 @@ struct GemmArgs {
   int force_cfg;
   long long split_stride;
   float* colsum;  // K-strided-A kernels only: slab [splitk][M] receiving sum_k A(m,k) (the bias gradient of nn.Linear)
+  const float* dq_a; const float* dq_b;  // fp8 kernel only: device scalars, the operands' de-quantisation factors (acc *= dq_a * dq_b)
+  int a_fmt;                             // fp8 kernel only: format of A (0 = e4m3, 1 = e5m2); B is e4m3
 };
 
 // ------------------------------------------------------------------------------------ epilogue
@@ -809,13 +811,14 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
   p.M = d.M; p.N = d.N; p.K = ga.K;
   p.c_dtype = CSMAE_F32; p.epi = EPI_RESID; p.splitk = ga.nsplit; p.tiles_m = 0; p.tiles_n = d.tiles_n; p.ktiles = ga.ktiles; p.ktiles_per_split = ga.ktiles_per_split;
   p.a_bytes = (unsigned)((long long)ga.K * d.ldy * 2); p.b_bytes = (unsigned)((long long)ga.K * d.ldx * 2);
-  p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db;
+  p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0;
   k64_tile<true, true, 256, true>(p, tm, tn, split, kt_begin, kt_end, DwFold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles});
 }
-// fold of the K slices of a grouped launch: workgroup (tile, quarter) adds the tile's slabs in slice order and accumulates 64 rows into
-// dW (16-byte accesses along rows); quarter 0 of the tn == 0 tiles does the same for the bias gradient.  Ordered: bit-reproducible.
+// fold of the K slices of a grouped launch: workgroup (tile, part) adds the tile's slabs in slice order and accumulates 16 rows into
+// dW (16-byte accesses along rows); part 0 of the tn == 0 tiles does the same for the bias gradient.  Ordered: bit-reproducible.
+#define DWR_PARTS 16
 __global__ __launch_bounds__(256) void dw_group_reduce_kernel(DwGroupArgs ga) {
-  const int tile_id = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  const int tile_id = blockIdx.x / DWR_PARTS, quarter = blockIdx.x % DWR_PARTS;
   DwDesc d = ga.d[0];
 #pragma unroll
   for (int i = 1; i < DW_GROUP_MAX; ++i) if (i < ga.n && tile_id >= ga.d[i].tile0) d = ga.d[i];
@@ -826,7 +829,9 @@ __global__ __launch_bounds__(256) void dw_group_reduce_kernel(DwGroupArgs ga) {
   const long long sstride = (long long)ga.total_tiles * 256 * 256;
   const float* base = ga.slab + (long long)tile_id * 256 * 256;
   const int n = n0 + c4 * 4;
-  for (int r = quarter * 64 + r0; r < quarter * 64 + 64; r += 4) {
+  constexpr int RPB = 256 / DWR_PARTS;
+#pragma unroll
+  for (int r = quarter * RPB + r0; r < quarter * RPB + RPB; r += 4) {
     const int m = m0 + r;
     if (m >= d.M || n >= d.N) continue;
     float* dst = d.dW + (long long)m * d.N + n;
@@ -842,6 +847,126 @@ __global__ __launch_bounds__(256) void dw_group_reduce_kernel(DwGroupArgs ga) {
       d.db[m] = a;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------ fp8 MFMA (BASELINE.json configs[4])
+// C[M,N] = dq_a * dq_b * sum_k A8(m,k) B8(n,k): both operands K-contiguous OCP fp8 bytes (A e4m3 or e5m2, B e4m3), per-tensor scales,
+// fp32 accumulation in v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) — 2.1x the bf16 MFMA rate (tools/mfma_rate_probe.hip) at
+// the SAME LDS bytes per K step: a 128-wide fp8 K step is the 128-byte row image of the pipelined bf16 kernel (16-B chunk swizzle
+// c ^ (row & 7)); lane (t, g) of a fragment owns the 32 bytes k = 32g .. 32g+31 of row t = two ds_read_b128.  Every fp8 product of the
+// step is brought into this one layout (dX reads a pre-transposed fp8 weight mirror), so there is no K-strided variant.
+// First version: two-stage LDS ring (2 x 64 KiB), LDS-DMA from inline asm, one barrier per K step, compiler-scheduled fragment reads.
+typedef int i8v_t __attribute__((ext_vector_type(8)));
+template <int AFMT>
+__global__ __launch_bounds__(512, 1) void gemm_fp8_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, WM = 128, WN = 64, NWN = 4, NW = 8, FM = 8, FN = 4, IMG = 256 * 128, STAGE = 2 * IMG;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = lane & 15, g = lane >> 4;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, tiles);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  // DMA: piece = 8 rows x 128 B; lane -> row (lane >> 3), physical chunk (lane & 7) = logical chunk ^ (row & 7); wave w owns pieces 4w .. 4w+3
+  const int l3 = lane >> 3, kc = ((lane & 7) ^ l3) * 16;
+  const int arow = m0 + w * 32 + l3, brow = n0 + w * 32 + l3;
+  const unsigned avo = (unsigned)((long long)arow * p.lda + kc), bvo = (unsigned)((long long)brow * p.ldb + kc);
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+    const bool kok = kt * 128 + kc < p.K;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned oa = (kok && arow + q * 8 < p.M) ? avo + (unsigned)(kt * 128) + (unsigned)(q * 8 * p.lda) : OOB_OFF;
+      lds_dma16(rsA, oa, base + (w * 4 + q) * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned ob = (kok && brow + q * 8 < p.N) ? bvo + (unsigned)(kt * 128) + (unsigned)(q * 8 * p.ldb) : OOB_OFF;
+      lds_dma16(rsB, ob, base + IMG + (w * 4 + q) * 1024);
+    }
+  };
+  f4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const int wm = (w / NWN) * WM, wn = (w % NWN) * WN;
+  const int ra0 = (wm + t) * 128, rb0 = (wn + t) * 128, sw = t & 7;   // (rows wm + 16 i + t share t's swizzle key)
+  const int c0 = ((2 * g) ^ sw) << 4, c1 = ((2 * g + 1) ^ sw) << 4;
+  auto frag = [&](const char* img, int roff) {
+    const u4_t lo = *reinterpret_cast<const u4_t*>(img + roff + c0), hi = *reinterpret_cast<const u4_t*>(img + roff + c1);
+    return i8v_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  const int nk = p.ktiles;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of K step kt have landed ...
+    __syncthreads();                                    // ... everybody's have, and everybody is done reading the other buffer
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const char* sa = smem + buf * STAGE;
+    const char* sb = sa + IMG;
+    i8v_t fb[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) fb[j] = frag(sb, rb0 + j * 2048);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const i8v_t fa = frag(sa, ra0 + i * 2048);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)   // operands swapped (D = B_frag x A_frag): a lane ends with 4 consecutive output columns; cbsz = B's format, blgp = A's
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], 0, AFMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+  }
+  const float alpha = (p.dq_a ? p.dq_a[0] : 1.f) * (p.dq_b ? p.dq_b[0] : 1.f);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] *= alpha;
+  __syncthreads();   // the ring becomes the epilogue strip
+  constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
+  void* Cptr = p.C;
+  float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
+#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+#define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+  const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
+                                                                                   : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));
+  if (p.c_dtype == CSMAE_BF16) {
+    if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
+    else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
+    else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
+    else EPI_CALL(bf16_t, EPI_NONE);
+  } else {
+    if (p.epi == EPI_GELU) EPI_CALL(float, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(float, EPI_DGELU);
+    else if (p.epi == EPI_RESID) EPI_CALL(float, EPI_RESID); else EPI_CALL(float, EPI_NONE);
+  }
+#undef EPI_CALL
+#undef EPI_CALL8
+}
+
+extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb,
+                              void* C, long long ldc, int c_dtype, const float* bias, int epilogue, void* aux, long long ldaux,
+                              const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* stream) {
+  CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && ldc % 4 == 0, "csmae_gemm_fp8: bad geometry M=%lld N=%lld K=%lld", M, N, K);
+  CSMAE_REQUIRE(a_fmt == 0 || a_fmt == 1, "csmae_gemm_fp8: a_fmt 0 (e4m3) or 1 (e5m2)");
+  CSMAE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_DGELU, "csmae_gemm_fp8: epilogue %d", epilogue);
+  CSMAE_REQUIRE(K % 16 == 0 && lda % 16 == 0 && ldb % 16 == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "csmae_gemm_fp8: K, lda, ldb multiples of 16 bytes, 16-byte aligned operands");
+  CSMAE_REQUIRE(!(epilogue == EPI_GELU || epilogue == EPI_DGELU) || (aux && ldaux % 4 == 0), "csmae_gemm_fp8: gelu epilogues need aux");
+  CSMAE_REQUIRE(epilogue != EPI_RESID || (resid && ldr % 4 == 0), "csmae_gemm_fp8: residual epilogue needs resid");
+  CSMAE_REQUIRE(M * lda < 0xFFFFFFF0ll && N * ldb < 0xFFFFFFF0ll, "csmae_gemm_fp8: operand larger than 4 GiB");
+  GemmArgs p;
+  p.force_cfg = 0; p.split_stride = 0; p.colsum = nullptr;
+  p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = 1;
+  p.a_bytes = (unsigned)(M * lda); p.b_bytes = (unsigned)(N * ldb);
+  p.ktiles = cdiv(K, 128); p.ktiles_per_split = p.ktiles;
+  p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
+  p.dq_a = dq_a; p.dq_b = dq_b; p.a_fmt = a_fmt;
+  dim3 grid(p.tiles_m * p.tiles_n);
+  if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_fp8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
+  return csmae_check_launch("csmae_gemm_fp8");
 }
 
 // ------------------------------------------------------------------------------------ fp32 exact
@@ -915,6 +1040,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
   p.force_cfg = g_force_cfg;
   p.split_stride = M * ldc;
   p.colsum = (epilogue == EPI_SPLIT && transA && transB && dtype == CSMAE_BF16) ? reinterpret_cast<float*>(aux) : nullptr;
+  p.dq_a = p.dq_b = nullptr; p.a_fmt = 0;
   p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;
@@ -1045,7 +1171,7 @@ extern "C" int csmae_gemm_dw_group(int dtype, int count, long long K, const void
   ga.slab = workspace; ga.cs_slab = workspace + (long long)ga.nsplit * tiles * 256 * 256;
   CSMAE_REQUIRE(ga.nsplit == 1 || ws_elems >= ga.nsplit * per_slice, "csmae_gemm_dw_group: workspace too small");
   hipLaunchKernelGGL(gemm_dw_group_kernel, dim3(tiles * ga.nsplit), dim3(512), 0, (hipStream_t)stream, ga);
-  if (ga.nsplit > 1) hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(tiles * 4), dim3(256), 0, (hipStream_t)stream, ga);
+  if (ga.nsplit > 1) hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(tiles * DWR_PARTS), dim3(256), 0, (hipStream_t)stream, ga);
   return csmae_check_launch("csmae_gemm_dw_group");
 }
 extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* dY, long long ldy, const void* X, long long ldx,

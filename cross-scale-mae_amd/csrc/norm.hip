@@ -126,22 +126,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
 // in a fixed order (no atomics: the result is bit-reproducible).  blockIdx.y walks a batch of LayerNorms whose partial rows lie
 // `stride` floats apart and whose dgamma / dbeta sit at goff[2k], goff[2k+1] floats behind `gbase` (the flat gradient buffer), so the
 // whole backward pass needs one launch per block stack instead of one per LayerNorm on its critical path.
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(int nblk, int D, const float* __restrict__ part, long long stride,
-                                                              float* __restrict__ gbase, const long long* __restrict__ goff,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(int nblk, int D, const float* __restrict__ part, long long stride,
+                                                               float* __restrict__ gbase, const long long* __restrict__ goff,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // 64 columns x 16 row lanes; a lane walks rows ty, ty + 16, ... with four loads in flight (a serial walk of 256 dependent rows per
+  // thread made this kernel 120 us long), the lanes are folded through LDS in lane order
+  __shared__ float red[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   const int k = blockIdx.y;
   part += (long long)k * stride;
   if (goff) { dgamma = gbase + goff[2 * k]; dbeta = gbase + goff[2 * k + 1]; }
-  float s = 0.f;
-  if (c < 2 * D)
-    for (int b = ty; b < nblk; b += 4) s += part[(long long)b * 2 * D + c];
-  red[ty][tx] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * D) {
+    int b = ty;
+    for (; b + 48 < nblk; b += 64) {
+      s0 += part[(long long)b * 2 * D + c]; s1 += part[(long long)(b + 16) * 2 * D + c];
+      s2 += part[(long long)(b + 32) * 2 * D + c]; s3 += part[(long long)(b + 48) * 2 * D + c];
+    }
+    for (; b < nblk; b += 16) s0 += part[(long long)b * 2 * D + c];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ty == 0 && c < 2 * D) {
-    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][tx];
     float* dst = c < D ? dgamma + c : dbeta + (c - D);
     *dst += s;
   }
@@ -189,7 +199,7 @@ static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, con
 #define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, (const TX*)dres_in, (TX*)dx_out, (TLP*)dx_lp, dgamma, dbeta, part)
   switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break; case 5: LNB(5); break; default: LNB(8); }
 #undef LNB
-  if (part && dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), 1), dim3(256), 0, st, blocks, D, part, 0ll, (float*)nullptr, (const long long*)nullptr, dgamma, dbeta);
+  if (part && dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), 1), dim3(1024), 0, st, blocks, D, part, 0ll, (float*)nullptr, (const long long*)nullptr, dgamma, dbeta);
 }
 
 extern "C" int csmae_layernorm_bwd(int dy_dtype, int x_dtype, int lp_dtype, long long M, int D, const void* dy, const void* x, const float* mean,
@@ -219,7 +229,7 @@ extern "C" int csmae_ln_param_reduce(int count, long long M, int D, const float*
                                      float* gbase, const long long* goff, void* stream) {
   CSMAE_REQUIRE(count > 0 && M > 0 && D > 0 && partials && gbase && goff && slice_elems >= 2ll * D, "csmae_ln_param_reduce: bad arguments");
   const int blocks = ln_bwd_blocks(M, D, slice_elems);
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), count), dim3(256), 0, (hipStream_t)stream, blocks, D, partials, stride, gbase, goff,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), count), dim3(1024), 0, (hipStream_t)stream, blocks, D, partials, stride, gbase, goff,
                      (float*)nullptr, (float*)nullptr);
   return csmae_check_launch("csmae_ln_param_reduce");
 }

@@ -56,6 +56,18 @@ int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* 
 int csmae_gemm_dw_group(int dtype, int count, long long K, const void* const* dY, const long long* ldy, const void* const* X,
                         const long long* ldx, float* const* dW, float* const* db, const long long* M, const long long* N, int slots,
                         float* workspace, long long ws_elems, void* stream);
+/* ---- fp8 MFMA path (BASELINE.json configs[4]: "fp8 MFMA GEMMs"; the same nn.Linear call sites, MAE_ViT_Baseline.py:160-188).
+ * OCP fp8, per-tensor scales: csmae_fp8_amax folds max|x| into a device scalar the caller zeroed; csmae_fp8_quantize writes
+ * q = fp8(x * FMAX / amax) (fmt 0 = e4m3, 1 = e5m2; transpose = 1 writes dst[c][r], the mirror of a weight the dX products read) and
+ * the de-quantisation factor dq = amax / FMAX; with amax_next the amax passed in is the previous step's (one pass over the tensor,
+ * out-of-range values saturate) and this step's is recorded for the next.  csmae_gemm_fp8: C[M,N] = dq_a * dq_b * sum_k A8(m,k) B8(n,k) with both operands
+ * K-contiguous fp8 bytes (A in a_fmt, B e4m3), fp32 accumulation (v_mfma_scale_f32_16x16x128_f8f6f4), epilogues of csmae_gemm. */
+int csmae_fp8_amax(int in_dtype, long long rows, int cols, const void* src, long long ld, float* amax, void* stream);
+int csmae_fp8_quantize(int in_dtype, int fmt, int transpose, long long rows, int cols, const void* src, long long ld, void* dst,
+                       long long ldd, const float* amax, float* dq, float* amax_next /* nullable: delayed scaling, += max|src| */, void* stream);
+int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb,
+                   void* C, long long ldc, int c_dtype, const float* bias, int epilogue, void* aux, long long ldaux,
+                   const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* stream);
 /* tuning hook for tools/gemm_bench.py: force the bf16 block tile (0: 128x128, 1: 256x128, 2: 256x256, -1: heuristic) */
 int csmae_gemm_force_tile(int cfg);
 

@@ -445,6 +445,63 @@ def test_fullsize_geometry_vs_reference_and_oracle(tag):
     assert all(torch.isfinite(p).all() for p in m.parameters())
 
 
+FP8_LOSS_RTOL = 1e-2     # fp8 MFMA path (e4m3 activations / weights, e5m2 gradients, per-tensor scales) vs the reference, total loss (measured 1e-3 .. 2e-3)
+FP8_GRAD_COS = 0.98      # cosine of every parameter gradient against the oracle's (2-bit-mantissa gradients in the dX products; measured worst 0.989, median 0.994)
+
+
+@pytest.mark.parametrize("tag", ["vith14_224", "vitb16_224"])
+def test_fp8_step_vs_reference_and_oracle(tag):
+    """BASELINE.json configs[4]: the transformer blocks' forward and dX GEMMs on the fp8 MFMA path (`compute_dtype = "fp8"`), at the
+    ViT-H/14 geometry that config is quoted on (and at ViT-B/16): total loss against the REFERENCE's (tests/golden/fullsize.*) within
+    FP8_LOSS_RTOL, masks bit-exact, parameter gradients against the oracle's by cosine, one fused AdamW step."""
+    import csmae_oracle as O
+    import fullsize_util as F
+    from csmae_hip.optim import FusedAdamW, add_weight_decay
+    meta, d = F.load(tag)
+    imgs = F.inputs(tag, meta)
+    m = F.seeded_model(meta)
+    osd = O.trainable_copy({k: v.detach().clone() for k, v in m.state_dict().items()})
+    cfg = O.make_cfg(input_size=meta["input_size"], input_channels=meta["channels"], patch_size=meta["patch"], variant="MsLdCeCd", **meta["geom"])
+    noise, box = [T(d["noise0"]), T(d["noise1"])], tuple(meta["box"])
+    oout = O.forward(osd, cfg, imgs, noise[0], noise[1], box)
+    oout["loss"].backward()
+    m = m.cuda().train()
+    m.compute_dtype = "fp8"
+    m._test_draws = dict(noise=noise, box=box)
+    loss, pred, mask = m(imgs.cuda(), mask_ratio=0.75)
+    loss.backward()
+    assert np.array_equal(mask.cpu().numpy().astype(np.uint8), d["mask"])
+    eng = m._engines["fp8"]
+    assert eng.fp8 and eng._fp8_site == 12 * (cfg["Ne"] + cfg["Nd"])         # every block GEMM went through fp8: 4 forward (x 2 view streams) + 4 dX per block
+    L = eng.ws.losses.cpu()
+    errs = dict(total=rel(L[0], meta["loss"]), recon_orig=rel(L[1], meta["recon"][0]), recon_crop=rel(L[2], meta["recon"][1]), cd=rel(L[3], meta["cd"]),
+                ce=rel(L[4], meta["ce"]))
+    assert errs["total"] < FP8_LOSS_RTOL and max(errs.values()) < 3 * FP8_LOSS_RTOL, (tag, errs)
+    cosines = {}
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        ref = osd[n].grad.flatten().double()
+        if float(ref.norm()) < 1e-7 * ref.numel() ** 0.5:
+            continue
+        cosines[n] = float(torch.nn.functional.cosine_similarity(p.grad.flatten().double().cpu(), ref, dim=0))
+    worst = min(cosines.items(), key=lambda kv: kv[1])
+    print(f"[fp8 {tag}] loss errors {({k: f'{v:.1e}' for k, v in errs.items()})}, worst gradient cosine {worst}, median {np.median(list(cosines.values())):.5f}")
+    assert worst[1] >= FP8_GRAD_COS, (tag, worst)
+    # second and third pass on the same weights: delayed scaling (each GEMM site quantises in one pass with the amax it saw one step
+    # earlier — here the same tensors, so the scales are the ones of the first pass and the loss must come out the same)
+    first = float(loss.detach())
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        m._test_draws = dict(noise=noise, box=box)
+        loss, _, _ = m(imgs.cuda(), mask_ratio=0.75)
+        loss.backward()
+        assert eng.ws.fp8_hist and abs(float(loss.detach()) - first) < 1e-3 * abs(first), (float(loss.detach()), first)
+    FusedAdamW(add_weight_decay(m, 0.05), lr=1e-4, betas=(0.9, 0.95)).step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
 def test_full_size_vitb_224_n128_properties():
     """BASELINE.json configs[1] at full size (ViT-B/16 MsLdCeCd, 224^2, 128 images, bf16 MFMA path) through properties that need no
     oracle run: masking indices are permutations in noise order with exactly L - keep masked patches per row; the step is deterministic

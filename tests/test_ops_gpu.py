@@ -163,6 +163,65 @@ def test_gemm_dw_group(ops, dtype, slots):
     assert_close(outs[0][k][2], 2 * (refs[k][0] - rnd(*shapes[k], seed=40 + k)), 1e-4, 2 * tol, "accumulating launches")
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("src_dtype", [torch.bfloat16, torch.float32])
+def test_fp8_quantize_matches_torch_float8(ops, fmt, src_dtype):
+    """Per-tensor current scaling into OCP fp8 (e4m3fn / e5m2): scale = FMAX / max|x| on the device, bytes equal to torch's own float8
+    conversion of the scaled tensor (round to nearest even), de-quantisation factor = max|x| / FMAX; transposed mirror = the same bytes
+    transposed."""
+    tdt, fmax = (torch.float8_e4m3fn, 448.0) if fmt == 0 else (torch.float8_e5m2, 57344.0)
+    for rows, cols in ((64, 128), (200, 520), (1284, 68)):
+        x = (rnd(rows, cols, seed=70) * 3.0).to(src_dtype)
+        x[3, 5] = 17.5   # the maximum
+        q = torch.empty(rows, cols, device="cuda", dtype=torch.uint8)
+        amax, dq = torch.zeros(1, device="cuda"), torch.empty(1, device="cuda")
+        ops.fp8_quantize(dev(x), q, amax, dq, fmt=fmt)
+        am = x.float().abs().max()
+        assert float(amax) == float(am) and abs(float(dq) - float(am) / fmax) <= 1e-6 * float(am) / fmax
+        scale = torch.tensor(fmax, dtype=torch.float32) / am
+        want = (x.float() * scale).clamp(-fmax, fmax).to(tdt).view(torch.uint8)
+        assert torch.equal(q.cpu(), want), (fmt, rows, cols, int((q.cpu() != want).sum()))
+        qt = torch.empty(cols, rows, device="cuda", dtype=torch.uint8)
+        amax.zero_()
+        ops.fp8_quantize(dev(x), qt, amax, dq, fmt=fmt, transpose=True)
+        assert torch.equal(qt.cpu(), want.t().contiguous())
+
+
+@pytest.mark.parametrize("a_fmt", [0, 1])
+def test_gemm_fp8_vs_fp32_on_the_quantised_operands(ops, a_fmt):
+    """csmae_gemm_fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation) against an fp32 matmul of the DE-QUANTISED operands: the
+    products are exact in fp32, so the two agree up to the order of the additions.  Asymmetric operands (a transposed or permuted
+    fragment layout would not pass), ragged M / N, K with a partial last K step, every epilogue the step uses."""
+    from csmae_hip import EPI_DGELU, EPI_GELU, EPI_RESID
+    adt = torch.float8_e4m3fn if a_fmt == 0 else torch.float8_e5m2
+    for M, N, K in ((256, 256, 128), (512, 768, 1280), (300, 520, 400), (1000, 264, 2048)):
+        a = rnd(M, K, seed=80) * (1.0 + torch.arange(K) / K)[None, :] + torch.arange(M)[:, None] / M
+        w = rnd(N, K, seed=81) * 0.05 + torch.arange(N)[:, None] / (8.0 * N)
+        a8 = torch.empty(M, K, device="cuda", dtype=torch.uint8)
+        w8 = torch.empty(N, K, device="cuda", dtype=torch.uint8)
+        am, dqa, wm, dqw = (torch.zeros(1, device="cuda") for _ in range(4))
+        ops.fp8_quantize(dev(a.to(torch.bfloat16)), a8, am, dqa, fmt=a_fmt)
+        ops.fp8_quantize(dev(w), w8, wm, dqw, fmt=0)
+        ad = a8.view(adt).float().cpu() * float(dqa)
+        wd = w8.view(torch.float8_e4m3fn).float().cpu() * float(dqw)
+        ref = ad.double() @ wd.double().t()
+        bias = rnd(N, seed=82)
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        ops.gemm_fp8(a8, w8, out, dqa, dqw, a_fmt=a_fmt, bias=dev(bias))
+        scale = float(ref.abs().max())
+        assert_close(out, (ref + bias).float(), 1e-5, 2e-5 * scale, f"fp8 gemm fp32 out {M}x{N}x{K}")
+        outb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        resid = rnd(M, N, seed=83).to(torch.bfloat16)
+        ops.gemm_fp8(a8, w8, outb, dqa, dqw, a_fmt=a_fmt, bias=dev(bias), epilogue=EPI_RESID, resid=dev(resid))
+        assert_close(outb, (ref + bias + resid.double()).float(), 1e-2, 1e-2 * scale, "fp8 gemm + residual (bf16 stream)")
+        aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_fp8(a8, w8, outb, dqa, dqw, a_fmt=a_fmt, bias=dev(bias), epilogue=EPI_GELU, aux=aux)
+        pre = (ref + bias).float()
+        assert_close(outb, torch.nn.functional.gelu(pre), 1e-2, 1e-2 * scale, "fp8 gemm + gelu")
+        ops.gemm_fp8(a8, w8, outb, dqa, dqw, a_fmt=a_fmt, epilogue=EPI_DGELU, aux=aux)
+        assert_close(outb, ref.float() * aux.float().cpu(), 1e-2, 1e-2 * scale, "fp8 gemm x gelu'")
+
+
 def test_gemm_rejects_bad_args(ops):
     import csmae_hip
     a = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)  # K = 12 not a multiple of 8

@@ -22,12 +22,15 @@ for k, d in sorted(res.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", 0) * 2 
     n = d.get("n_FETCH_SIZE", 1)
     f = d.get("FETCH_SIZE", 0) * 2 / n / 1024; w = d.get("WRITE_SIZE", 0) / max(1, d.get("n_WRITE_SIZE", 1)) / 1024
     lines.append(f"{k[:70]:70s} {n:8d} {f:10.2f} {w:10.2f} {d.get('dur_FETCH_SIZE', 0) / n / 1e3:9.1f}")
-    if k.startswith("gemm_bf16"):
+    if k.startswith("gemm_"):
         gem["f"] += d.get("FETCH_SIZE", 0) * 2 / 1024; gem["w"] += d.get("WRITE_SIZE", 0) / 1024; gem["n"] += n
 txt = "\n".join(lines) + "\n"
 print(txt)
 if len(sys.argv) > 4:
     open(sys.argv[4], "w").write(txt)
 if len(sys.argv) > 5:
-    json.dump({"step_hbm_gb": round(tf + tw, 2), "gemm_bf16_mb_per_launch": round((gem["f"] + gem["w"]) / max(1, gem["n"]), 2),
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash   # the profile is valid for exactly these kernel sources (bench.py refuses a stale one)
+    json.dump({"step_hbm_gb": round(tf + tw, 2), "gemm_mb_per_launch": round((gem["f"] + gem["w"]) / max(1, gem["n"]), 2), "csrc_sha256": csrc_hash(),
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 (gfx950), " + sys.argv[4]}, open(sys.argv[5], "w"))
