@@ -389,8 +389,9 @@ def test_stack_boundaries_bf16_stream(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_bnrelu_token_axis(ops, dtype):
-    N, L, Hp = 6, 9, 64
+@pytest.mark.parametrize("geom", [(6, 9, 64), (37, 5, 2048), (3, 4, 100)])
+def test_bnrelu_token_axis(ops, dtype, geom):
+    N, L, Hp = geom   # (37, 5, 2048): the unrolled bf16 fast path at the predictor's width; (3, 4, 100): the generic kernels
     u = (rnd(N * L, Hp, seed=40) * 1.5 + 0.3).to(dtype)
     gamma, beta = rnd(L, seed=41) * 0.3 + 1.0, rnd(L, seed=42) * 0.2
     dr = rnd(N * L, Hp, seed=43).to(dtype)
