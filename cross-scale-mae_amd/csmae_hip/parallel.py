@@ -23,23 +23,26 @@ def is_dist() -> bool:
 class GradSync:
     """Mean-all-reduce of contiguous ranges of a flat gradient buffer, optionally on a side stream."""
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, comm_dtype: Optional[torch.dtype] = None):
+    def __init__(self, flat_grad: torch.Tensor, group=None, comm_dtype: Optional[torch.dtype] = None, force: bool = False):
         self.g = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if is_dist() else 1
+        self.force = force and is_dist()   # issue the collectives even at world size 1 (stream / event ordering under test on one GPU)
         self.comm_dtype = comm_dtype
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
         self._staging = torch.empty(flat_grad.numel(), dtype=comm_dtype, device=flat_grad.device) if comm_dtype not in (None, flat_grad.dtype) else None
         self._pending = False
+        self.issued = []   # (lo, hi) of the ranges exchanged since the last finish() (tests read it)
         # gloo has no AVG; RCCL does
         self._avg = self.cuda and is_dist() and dist.get_backend(group) == "nccl"
 
     def reduce_range(self, lo: int, hi: int):
         """Enqueue mean-all-reduce of g[lo:hi].  On GPU it runs on the side stream after everything already enqueued on the
         current stream (the kernels that produced g[lo:hi])."""
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.force) or hi <= lo:
             return
+        self.issued.append((lo, hi))
         seg = self.g[lo:hi]
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -70,7 +73,7 @@ class GradSync:
             self._pending = False
 
     def broadcast(self, tensors: List[torch.Tensor], src: int = 0):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for t in tensors:
             dist.broadcast(t, src=src, group=self.group)
@@ -138,17 +141,27 @@ class DataParallel(torch.nn.Module):
     """Wrapper with DDP's surface (`.module`, forward passthrough, `no_sync()`): hooks the engine's backward so gradient
     ranges are all-reduced as soon as they are final."""
 
-    def __init__(self, module, device_ids=None, find_unused_parameters=False, comm_dtype: Optional[torch.dtype] = None, **_):
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, comm_dtype="auto", force_collectives: bool = False, **_):
+        """comm_dtype: gradient payload on the wire.  "auto" (default): bf16 when the model computes in bf16 / fp8 (throughput mode:
+        the weight gradients come out of bf16 operands anyway, and half the xGMI bytes is what SURVEY §8e's budget needs), fp32 in
+        parity mode; or an explicit torch dtype / None (= fp32)."""
         super().__init__()
         self.module = module
         self.comm_dtype = comm_dtype
+        self.force_collectives = force_collectives
         self.require_backward_grad_sync = True
         self._sync: Optional[GradSync] = None
         module.__dict__["_dp"] = self  # plain attribute (not a registered submodule: that would make the module tree cyclic)
 
     def _ensure(self, flat):
         if self._sync is None or self._sync.g is not flat.g:
-            self._sync = GradSync(flat.g, comm_dtype=self.comm_dtype)
+            cd = self.comm_dtype
+            if isinstance(cd, str):   # "auto"
+                mode = self.module.compute_dtype
+                if mode is None:
+                    mode = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+                cd = None if mode == torch.float32 else torch.bfloat16
+            self._sync = GradSync(flat.g, comm_dtype=cd, force=self.force_collectives)
             # rank-0 parameters and buffers win (DDP constructor semantics, main_pretrain.py:418-420)
             self._sync.broadcast([flat.p])
             self._broadcast_buffers()
@@ -174,6 +187,8 @@ class DataParallel(torch.nn.Module):
 
     def wants(self, name) -> bool:
         """True if `name` closes a bucket (lets the engine skip joining its weight-gradient stream otherwise)."""
+        if self._sync is None and is_dist() and self.module._flat is not None:
+            self._ensure(self.module._flat)
         return self.require_backward_grad_sync and is_dist() and self._sync is not None and name in self._ranges
 
     def backward_done(self, flat):

@@ -85,7 +85,8 @@ def get_args_parser():
     p.add_argument("--synthetic_len", type=int, default=64, help="iterations per epoch of the synthetic loader")
     p.add_argument("--input_channels", type=int, default=None, help="bands of the synthetic loader / model (reference constructors default to 3)")
     p.add_argument("--honor_start_epoch", action="store_true", help="start the epoch loop at --start_epoch / the resumed epoch")
-    p.add_argument("--grad_comm_dtype", type=str, default="fp32", choices=["fp32", "bf16"], help="RCCL gradient payload")
+    p.add_argument("--grad_comm_dtype", type=str, default="auto", choices=["auto", "fp32", "bf16"],
+                   help="RCCL gradient payload; auto = bf16 under autocast (the bf16 MFMA path), fp32 otherwise")
     return p
 
 
@@ -191,7 +192,7 @@ def main(args):
     from csmae_hip.parallel import DataParallel
     if args.distributed:
         model = DataParallel(model, device_ids=[args.gpu], find_unused_parameters=True,
-                             comm_dtype=torch.bfloat16 if args.grad_comm_dtype == "bf16" else None)
+                             comm_dtype={"auto": "auto", "bf16": torch.bfloat16, "fp32": None}[args.grad_comm_dtype])
         model_without_ddp = model.module
     optimizer = FusedAdamW(add_weight_decay(model_without_ddp, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))
     print(optimizer)
