@@ -1,0 +1,15 @@
+#!/bin/bash
+# Everything the judged profiles/ files come from, on one box: default bench line, kernel stats of the same command (overlapped and
+# serialised), HBM-traffic PMC passes, preset lines.  usage: tools/profile_round.sh TAG
+tag=$1; out=gpurun_out/$tag; mkdir -p $out
+export TMPDIR=/tmp
+timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
+python tools/rocpd_stats.py $(find /tmp/prof_$tag -name '*.db' | head -1) $out/step_kernel_stats.txt > /dev/null
+python tools/step_timeline.py $(find /tmp/prof_$tag -name '*.db' | head -1) > $out/step_timeline.txt 2>&1
+( cd /tmp && CSMAE_DW_MAIN=1 CSMAE_FWD_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profs_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
+python tools/rocpd_stats.py $(find /tmp/profs_$tag -name '*.db' | head -1) $out/step_serialised_kernel_stats.txt > /dev/null
+bash tools/pmc_round.sh $tag > /dev/null 2>&1
+for p in large large4; do timeout 600 python bench.py --preset $p --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out/bench_presets.txt; done
+for d in bf16 fp8; do timeout 600 python bench.py --preset huge14 --dtype $d --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out/bench_presets.txt; done
+cut -c1-300 $out/bench_default.json; head -4 $out/pmc_hbm_traffic.txt
