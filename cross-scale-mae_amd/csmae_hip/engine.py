@@ -138,7 +138,8 @@ class Workspace:
 
         def stack(nl, M, Dm, H):
             return dict(x=E(nl + 1, M, Dm, **rs), xm=E(nl, M, Dm, **rs), y1=E(nl, M, Dm, **lp), y2=E(nl, M, Dm, **lp),
-                        qkv=E(nl, M, 3 * Dm, **lp), o=E(nl, M, Dm, **lp), pre=E(nl, M, 4 * Dm, **lp), h=E(nl, M, 4 * Dm, **lp),
+                        qkv=E(nl, M, 3 * Dm, **lp), o=E(nl, M, Dm, **lp), h=E(nl, M, 4 * Dm, **lp),
+                        pre=E(nl, M, 4 * Dm, device=dev, dtype=torch.uint8 if eng.gp_q8 else T),   # gelu'(pre-activation): one byte per element in throughput mode
                         st=E(nl, 4, M, **f32), lse=E(nl, M * H, **f32))
         self.enc = stack(c["Ne"], Me, D, c["He"])
         self.dec = stack(c["Nd"], Md, Dd, c["Hd"])
@@ -226,6 +227,7 @@ class Engine:
         # residual epilogues, LayerNorm forward / backward and the stack boundaries move half the bytes (they are HBM- / store-bound,
         # DESIGN §4).  CSMAE_RESID_FP32=1 keeps the fp32 stream under the bf16 GEMMs (what torch autocast does; A/B aid).
         self.res_dtype = torch.float32 if (self.T == F32 or os.environ.get("CSMAE_RESID_FP32")) else torch.bfloat16
+        self.gp_q8 = self.T == BF16 and not os.environ.get("CSMAE_GP_BF16")   # gelu' saved as 8-bit codes (csmae.h CSMAE_EPI_GELU_Q8); env: A/B aid
         v = cfg["variant"]
         self.views = 1 if v == "Baseline" else 2
         self.has_pred = v in ("MsLdCd", "MsLdLeCd", "MsLdCeCd")

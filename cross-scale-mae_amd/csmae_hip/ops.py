@@ -71,6 +71,8 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NON
     assert K == Kb and out.shape[0] == M and out.shape[1] == N, (a.shape, b.shape, out.shape, trans_a, trans_b)
     assert a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
     assert resid is None or resid.dtype == out.dtype, "the residual epilogue reads its addend in the output's dtype"
+    if aux is not None and aux.dtype == torch.uint8:   # gelu' as one byte per element (CSMAE_EPI_GELU_Q8 / CSMAE_EPI_DGELU_Q8)
+        epilogue = {EPI_GELU: 6, EPI_DGELU: 7}[epilogue]
     if _timer is not None:
         _timer.begin()
     check(load().csmae_gemm(dt(a), int(trans_a), int(trans_b), M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0),
@@ -118,6 +120,8 @@ def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI
     N = b8.shape[0]
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == K and out.shape == (M, N)
     assert resid is None or resid.dtype == out.dtype
+    if aux is not None and aux.dtype == torch.uint8:
+        epilogue = {EPI_GELU: 6, EPI_DGELU: 7}[epilogue]
     if _timer is not None:
         _timer.begin()
     check(load().csmae_gemm_fp8(a_fmt, M, N, K, _p(a8), a8.stride(0), _p(b8), b8.stride(0), _p(out), out.stride(0), dt(out), _p(bias), epilogue,

@@ -44,7 +44,26 @@ struct GemmArgs {
   float* colsum;  // K-strided-A kernels only: slab [splitk][M] receiving sum_k A(m,k) (the bias gradient of nn.Linear)
   const float* dq_a; const float* dq_b;  // fp8 kernel only: device scalars, the operands' de-quantisation factors (acc *= dq_a * dq_b)
   int a_fmt;                             // fp8 kernel only: format of A (0 = e4m3, 1 = e5m2); B is e4m3
+  int aux_q8;                            // GELU / DGELU epilogues: aux (gelu') is one byte per element (GP_Q8 code below) instead of C's dtype
 };
+
+// gelu'(x) lies in [-0.129, 1.129]: stored as q = round((g + 0.13) * 255 / 1.26) it costs one byte instead of two in the two epilogues
+// that are bound by their HBM bytes (fc1 writes h and gelu', fc2-backward reads gelu' and writes dpre: -25 % each); |error| <= 2.5e-3,
+// the size of a bf16 rounding step at 1.
+#define GP_Q8_SCALE (255.0f / 1.26f)
+#define GP_Q8_OFF 0.13f
+__device__ __forceinline__ unsigned gp_q8_pack4(f4_t g) {
+  unsigned p = 0;
+  p = __builtin_amdgcn_cvt_pk_u8_f32((g[0] + GP_Q8_OFF) * GP_Q8_SCALE, 0, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32((g[1] + GP_Q8_OFF) * GP_Q8_SCALE, 1, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32((g[2] + GP_Q8_OFF) * GP_Q8_SCALE, 2, p);
+  p = __builtin_amdgcn_cvt_pk_u8_f32((g[3] + GP_Q8_OFF) * GP_Q8_SCALE, 3, p);
+  return p;
+}
+__device__ __forceinline__ f4_t gp_q8_unpack4(unsigned p) {
+  const f4_t q = {(float)(p & 0xffu), (float)((p >> 8) & 0xffu), (float)((p >> 16) & 0xffu), (float)(p >> 24)};
+  return q * (1.0f / GP_Q8_SCALE) - GP_Q8_OFF;
+}
 
 // ------------------------------------------------------------------------------------ epilogue
 template <typename TC>
@@ -146,6 +165,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, void* Cptr, f4_
     for (int ps = 0; ps < NPASS; ++ps) {
       const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
       if (EPI == EPI_RESID) ld[slot0 + ps] = ld4<TC>(reinterpret_cast<const TC*>(p.resid) + (long long)gm * p.ldr + gnc);
+      else if (p.aux_q8) ld[slot0 + ps] = gp_q8_unpack4(*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(p.aux) + (long long)gm * p.ldaux + gnc));
       else ld[slot0 + ps] = ld4<TC>(reinterpret_cast<const TC*>(p.aux) + (long long)gm * p.ldaux + gnc);
     }
   };
@@ -175,7 +195,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, void* Cptr, f4_
       if (EPI == EPI_RESID) o = v + ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
       if (EPI == EPI_DGELU) o = v * ld[(PRELOAD_ALL ? part * NPASS : 0) + ps];
       if (colok && gm < p.M) {
-        if (EPI == EPI_GELU) st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)gm * p.ldaux + gn, v);
+        if (EPI == EPI_GELU) {
+          if (p.aux_q8) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.aux) + (long long)gm * p.ldaux + gn) = gp_q8_pack4(v);
+          else st4<TC>(reinterpret_cast<TC*>(p.aux) + (long long)gm * p.ldaux + gn, v);
+        }
         st4<TC>(reinterpret_cast<TC*>(Cptr) + (long long)gm * p.ldc + gn, o);
       }
     }
@@ -206,7 +229,12 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
         const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
         const bf16_t* src = LS + (long long)gm * lds_ + gn;
         ld[ps] = make_uint4(0, 0, 0, 0);
-        if (ok1) ld[ps] = *reinterpret_cast<const uint4*>(src);
+        if (EPI == EPI_DGELU && p.aux_q8) {   // one byte per element: 8 (4) bytes per lane
+          const unsigned char* s8 = reinterpret_cast<const unsigned char*>(p.aux) + (long long)gm * p.ldaux + gn;
+          if (ok1) { const uint2 h = *reinterpret_cast<const uint2*>(s8); ld[ps].x = h.x; ld[ps].y = h.y; }
+          else if (ok0) ld[ps].x = *reinterpret_cast<const unsigned*>(s8);
+        }
+        else if (ok1) ld[ps] = *reinterpret_cast<const uint4*>(src);
         else if (ok0) { const uint2 h = *reinterpret_cast<const uint2*>(src); ld[ps].x = h.x; ld[ps].y = h.y; }
       }
     }
@@ -225,16 +253,22 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
       if (EPI == EPI_GELU) { const f4_t x0 = v0, x1 = v1; gelu_both4<bf16_t>(x0, o0, v0); gelu_both4<bf16_t>(x1, o1, v1); }
       if (EPI == EPI_DGELU || EPI == EPI_RESID) {
         const uint4 a = ld[ps];
-        const f4_t a0 = f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
-        const f4_t a1 = f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
+        f4_t a0 = f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+        f4_t a1 = f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
+        if (EPI == EPI_DGELU && p.aux_q8) { a0 = gp_q8_unpack4(a.x); a1 = gp_q8_unpack4(a.y); }
         if (EPI == EPI_DGELU) { o0 = v0 * a0; o1 = v1 * a1; } else { o0 = v0 + a0; o1 = v1 + a1; }
       }
       if (gm < p.M) {
+        if (EPI == EPI_GELU && p.aux_q8) {
+          unsigned char* d8 = reinterpret_cast<unsigned char*>(p.aux) + (long long)gm * p.ldaux + gn;
+          if (ok1) *reinterpret_cast<uint2*>(d8) = make_uint2(gp_q8_pack4(v0), gp_q8_pack4(v1));
+          else if (ok0) *reinterpret_cast<unsigned*>(d8) = gp_q8_pack4(v0);
+        }
         if (ok1) {
-          if (EPI == EPI_GELU) *reinterpret_cast<uint4*>(X + (long long)gm * p.ldaux + gn) = make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
+          if (EPI == EPI_GELU && !p.aux_q8) *reinterpret_cast<uint4*>(X + (long long)gm * p.ldaux + gn) = make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
           *reinterpret_cast<uint4*>(C + (long long)gm * p.ldc + gn) = make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
         } else if (ok0) {
-          if (EPI == EPI_GELU) st4<bf16_t>(X + (long long)gm * p.ldaux + gn, v0);
+          if (EPI == EPI_GELU && !p.aux_q8) st4<bf16_t>(X + (long long)gm * p.ldaux + gn, v0);
           st4<bf16_t>(C + (long long)gm * p.ldc + gn, o0);
         }
       }
@@ -811,7 +845,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
   p.M = d.M; p.N = d.N; p.K = ga.K;
   p.c_dtype = CSMAE_F32; p.epi = EPI_RESID; p.splitk = ga.nsplit; p.tiles_m = 0; p.tiles_n = d.tiles_n; p.ktiles = ga.ktiles; p.ktiles_per_split = ga.ktiles_per_split;
   p.a_bytes = (unsigned)((long long)ga.K * d.ldy * 2); p.b_bytes = (unsigned)((long long)ga.K * d.ldx * 2);
-  p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0;
+  p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = 0;
   k64_tile<true, true, 256, true>(p, tm, tn, split, kt_begin, kt_end, DwFold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles});
 }
 // fold of the K slices of a grouped launch: workgroup (tile, part) adds the tile's slabs in slice order and accumulates 16 rows into
@@ -949,6 +983,9 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
                               const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && ldc % 4 == 0, "csmae_gemm_fp8: bad geometry M=%lld N=%lld K=%lld", M, N, K);
   CSMAE_REQUIRE(a_fmt == 0 || a_fmt == 1, "csmae_gemm_fp8: a_fmt 0 (e4m3) or 1 (e5m2)");
+  const int q8 = (epilogue == 6 || epilogue == 7);
+  if (q8) epilogue = epilogue == 6 ? EPI_GELU : EPI_DGELU;
+  CSMAE_REQUIRE(!q8 || c_dtype == CSMAE_BF16, "csmae_gemm_fp8: the 8-bit gelu' epilogues write bf16");
   CSMAE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_DGELU, "csmae_gemm_fp8: epilogue %d", epilogue);
   CSMAE_REQUIRE(K % 16 == 0 && lda % 16 == 0 && ldb % 16 == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "csmae_gemm_fp8: K, lda, ldb multiples of 16 bytes, 16-byte aligned operands");
   CSMAE_REQUIRE(!(epilogue == EPI_GELU || epilogue == EPI_DGELU) || (aux && ldaux % 4 == 0), "csmae_gemm_fp8: gelu epilogues need aux");
@@ -962,7 +999,7 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
   p.a_bytes = (unsigned)(M * lda); p.b_bytes = (unsigned)(N * ldb);
   p.ktiles = cdiv(K, 128); p.ktiles_per_split = p.ktiles;
   p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
-  p.dq_a = dq_a; p.dq_b = dq_b; p.a_fmt = a_fmt;
+  p.dq_a = dq_a; p.dq_b = dq_b; p.a_fmt = a_fmt; p.aux_q8 = q8;
   dim3 grid(p.tiles_m * p.tiles_n);
   if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gemm_fp8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
@@ -1031,6 +1068,9 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
                           int splitk, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0, "csmae_gemm: empty problem M=%lld N=%lld K=%lld", M, N, K);
   CSMAE_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "csmae_gemm: N and ldc must be multiples of 4 (N=%lld ldc=%lld)", N, ldc);
+  const int q8 = (epilogue == 6 || epilogue == 7);   // CSMAE_EPI_GELU_Q8 / CSMAE_EPI_DGELU_Q8: gelu' as one byte per element
+  if (q8) epilogue = epilogue == 6 ? EPI_GELU : EPI_DGELU;
+  CSMAE_REQUIRE(!q8 || (dtype == CSMAE_BF16 && c_dtype == CSMAE_BF16), "csmae_gemm: the 8-bit gelu' epilogues belong to the bf16 path");
   CSMAE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_SPLIT, "csmae_gemm: bad epilogue %d", epilogue);
   CSMAE_REQUIRE((epilogue != EPI_ATOMIC && epilogue != EPI_SPLIT) || c_dtype == CSMAE_F32, "csmae_gemm: split-K accumulate needs fp32 C");
   CSMAE_REQUIRE(!(epilogue == EPI_GELU || epilogue == EPI_DGELU) || (aux && ldaux % 4 == 0), "csmae_gemm: gelu epilogues need aux");
@@ -1040,7 +1080,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
   p.force_cfg = g_force_cfg;
   p.split_stride = M * ldc;
   p.colsum = (epilogue == EPI_SPLIT && transA && transB && dtype == CSMAE_BF16) ? reinterpret_cast<float*>(aux) : nullptr;
-  p.dq_a = p.dq_b = nullptr; p.a_fmt = 0;
+  p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = q8;
   p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;

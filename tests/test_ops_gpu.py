@@ -355,6 +355,30 @@ def test_gemm_residual_epilogue_bf16_stream(ops):
             ops.gemm(dev(a), dev(w), out, bias=dev(bias), epilogue=EPI_RESID, resid=dev(resid.float()))
 
 
+def test_gemm_gelu_epilogues_with_8bit_derivative(ops):
+    """fc1 epilogue: C = gelu(x), aux = gelu'(x) stored as one byte (q = round((g + 0.13) * 255 / 1.26)); fc2-backward epilogue: C = acc * aux.
+    The code's resolution is 1.26 / 255 = 4.9e-3, i.e. |error| <= 2.5e-3; on the pipelined-kernel shapes and on a small one."""
+    from csmae_hip import EPI_DGELU, EPI_GELU
+    for M, N, K in ((512, 1024, 256), (400, 520, 192), (64, 128, 64)):
+        a = rnd(M, K, seed=90).to(torch.bfloat16)
+        w = (rnd(N, K, seed=91) * 0.12).to(torch.bfloat16)
+        bias = rnd(N, seed=92) * 0.5
+        h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        gq = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+        ops.gemm(dev(a), dev(w), h, bias=dev(bias), epilogue=EPI_GELU, aux=gq)
+        x = (a.float() @ w.float().t() + bias).requires_grad_(True)
+        ref_h = torch.nn.functional.gelu(x)
+        ref_h.sum().backward()
+        assert_close(h, ref_h, 1e-2, 1e-2, f"gelu {M}x{N}")
+        dec = gq.float().cpu() * (1.26 / 255.0) - 0.13
+        assert float((dec - x.grad).abs().max()) <= 2.5e-3 + 2e-3, float((dec - x.grad).abs().max())   # code step / 2 + the bf16-GELU approximation
+        dy = rnd(M, N, seed=93).to(torch.bfloat16)          # backward: dpre = (dy W2) * gelu' with dy [M, N2] -> here: a generic product times aux
+        w2 = (rnd(N, N, seed=94) * 0.05).to(torch.bfloat16) if N <= 1024 else None
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(dev(dy), dev(w2), out, trans_b=True, epilogue=EPI_DGELU, aux=gq)
+        assert_close(out, (dy.float() @ w2.float()) * dec, 1e-2, 2e-2, f"dgelu q8 {M}x{N}")
+
+
 def test_stack_boundaries_bf16_stream(ops):
     """embed_assemble / unshuffle_fwd write, embed_assemble_bwd / unshuffle_bwd read the bf16 residual stream; bf16 -> fp32 cast."""
     B2, keep, D, L = 4, 5, 64, 16

@@ -15,22 +15,26 @@ ME, MD = 12800, 50432
 CASES = [
     # name, layout, M, N, K, epilogue, out_dtype
     ("enc.qkv      fwd", "NT", ME, 2304, 768, 0, torch.bfloat16),
-    ("enc.proj     fwd", "NT", ME, 768, 768, 2, torch.float32),
+    ("enc.proj     fwd", "NT", ME, 768, 768, 2, torch.bfloat16),
     ("enc.fc1+gelu fwd", "NT", ME, 3072, 768, 1, torch.bfloat16),
-    ("enc.fc2      fwd", "NT", ME, 768, 3072, 2, torch.float32),
+    ("enc.fc2      fwd", "NT", ME, 768, 3072, 2, torch.bfloat16),
     ("dec.qkv      fwd", "NT", MD, 1536, 512, 0, torch.bfloat16),
-    ("dec.proj     fwd", "NT", MD, 512, 512, 2, torch.float32),
+    ("dec.proj     fwd", "NT", MD, 512, 512, 2, torch.bfloat16),
     ("dec.fc1+gelu fwd", "NT", MD, 2048, 512, 1, torch.bfloat16),
-    ("dec.fc2      fwd", "NT", MD, 512, 2048, 2, torch.float32),
+    ("dec.fc2      fwd", "NT", MD, 512, 2048, 2, torch.bfloat16),
     ("enc.fc2  dX+dgelu", "NN", ME, 3072, 768, 3, torch.bfloat16),
     ("enc.fc1  dX", "NN", ME, 768, 3072, 0, torch.bfloat16),
     ("enc.qkv  dX", "NN", ME, 768, 2304, 0, torch.bfloat16),
     ("dec.fc2  dX+dgelu", "NN", MD, 2048, 512, 3, torch.bfloat16),
     ("dec.fc1  dX", "NN", MD, 512, 2048, 0, torch.bfloat16),
     ("dec.qkv  dX", "NN", MD, 512, 1536, 0, torch.bfloat16),
+    ("enc.proj dX", "NN", ME, 768, 768, 0, torch.bfloat16),
+    ("dec.proj dX", "NN", MD, 512, 512, 0, torch.bfloat16),
     ("enc.fc1  dW", "TN", 3072, 768, ME, 4, torch.float32),
     ("enc.qkv  dW", "TN", 2304, 768, ME, 4, torch.float32),
     ("enc.proj dW", "TN", 768, 768, ME, 4, torch.float32),
+    ("enc.fc2  dW", "TN", 768, 3072, ME, 4, torch.float32),
+    ("dec.qkv  dW", "TN", 1536, 512, MD, 4, torch.float32),
     ("dec.fc1  dW", "TN", 2048, 512, MD, 4, torch.float32),
     ("dec.fc2  dW", "TN", 512, 2048, MD, 4, torch.float32),
     ("dec.proj dW", "TN", 512, 512, MD, 4, torch.float32),
@@ -61,7 +65,7 @@ def main():
         C = torch.zeros(M, N, device=dev, dtype=odt)
         bias = torch.randn(N, device=dev) if epi in (0, 1, 2) else None
         aux = torch.randn(M, N, device=dev).to(odt) if epi in (1, 3) else None
-        resid = torch.randn(M, N, device=dev) if epi == 2 else None
+        resid = torch.randn(M, N, device=dev).to(odt) if epi == 2 else None   # (the residual stream: bf16 in throughput mode)
         sk = 1
         if epi == 4:
             sk = a.splitk or Engine._splitk(M, N, K, 128, 64)
