@@ -27,12 +27,12 @@ _SIGNATURES = {
     "csmae_gemm_dw_group": [I, I, L, P, P, P, P, P, P, P, P, I, P, L, P],
     "csmae_fp8_amax": [I, L, I, P, L, P, P],
     "csmae_fp8_quantize": [I, I, I, L, I, P, L, P, L, P, P, P, P],
-    "csmae_gemm_fp8": [I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P, P, P],
+    "csmae_gemm_fp8": [I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P, P, P, L, I, P, P, P, P],
     "csmae_gemm_force_tile": [I],
     "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
-    "csmae_layernorm_fwd": [I, I, L, I, P, P, P, F, P, P, P, P, P],
-    "csmae_layernorm_bwd": [I, I, I, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P],
+    "csmae_layernorm_fwd": [I, I, L, I, P, P, P, F, P, P, P, P, P, I, P, P, P, P],
+    "csmae_layernorm_bwd": [I, I, I, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P, I, P, P, P, P],
     "csmae_ln_param_reduce": [I, L, I, P, L, L, P, P, P],
     "csmae_bnrelu_fwd": [I, I, I, I, P, P, P, F, F, P, P, P, P, P, P, I, P],
     "csmae_bnrelu_bwd": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],

@@ -203,7 +203,9 @@ class Workspace:
             big8 = max(Me * 4 * D, Md * 4 * Dd)
             self.a8 = [E(big8, device=dev, dtype=torch.uint8) for _ in range(2)]
             nsite = 8 * (c["Ne"] + c["Nd"]) * 2 + 16
-            self.fp8_amax = [torch.zeros(nsite, **f32), torch.zeros(nsite, **f32)]   # this step's / the previous step's max|x| per GEMM site
+            self.fp8_amax = [torch.zeros(nsite, ops.FP8_SLOTS, **f32), torch.zeros(nsite, ops.FP8_SLOTS, **f32)]   # this step's / the previous step's max|x| per GEMM site (64 partial maxima each)
+            self.q_b = [E(big8, device=dev, dtype=torch.uint8) for _ in range(2)]   # fp8 copies emitted by the fc1 / fc2-backward epilogues (h, dpre)
+            self.q_a = [E(big8 // 4, device=dev, dtype=torch.uint8) for _ in range(2)]  # ... by LayerNorm forward (y1, y2) / backward (the residual gradient)
             self.fp8_dq = torch.ones(nsite, **f32)
             self.fp8_hist = False    # the previous step's amax exist (delayed scaling from the second step on)
             self.fp8_complete = False
@@ -217,6 +219,9 @@ class Engine:
         # (per-tensor scaled OCP fp8 operands: activations / weights e4m3, gradients e5m2; fp32 accumulation; weight gradients stay bf16)
         self.fp8 = act_dtype == "fp8"
         self._fp8_site = 0
+        self._fp8_cur = None    # (site, fp8 bytes or None) of the residual gradient the next block's fc2-backward product reads
+        self._fp8_fuse_lnb = not os.environ.get("CSMAE_FP8_NO_FUSE_LNB")
+        self._fp8_fuse = not os.environ.get("CSMAE_FP8_NO_FUSE")   # A/B aid: every fp8 operand through the separate quantisation pass
         if self.fp8:
             act_dtype = torch.bfloat16
         if self.device.type != "cuda":
@@ -305,14 +310,14 @@ class Engine:
             f.w8 = torch.zeros(f.total, device=self.device, dtype=torch.uint8)
             f.w8t = torch.zeros(f.total, device=self.device, dtype=torch.uint8)
             f.w8_idx = {n: k for k, n in enumerate(self._fp8_names())}
-            f.w8_amax = torch.zeros(len(f.w8_idx), device=self.device)
+            f.w8_amax = torch.zeros(len(f.w8_idx), ops.FP8_SLOTS, device=self.device)
             f.w8_dq = torch.ones(len(f.w8_idx), device=self.device)
         f.w8_amax.zero_()
         for n, k in f.w8_idx.items():
             o, cnt, shape = f.slots[n]
             w = f.p[o:o + cnt].view(shape)
-            ops.fp8_quantize(w, f.w8[o:o + cnt].view(shape), f.w8_amax[k:k + 1], f.w8_dq[k:k + 1])
-            ops.fp8_quantize(w, f.w8t[o:o + cnt].view(shape[1], shape[0]), f.w8_amax[k:k + 1], f.w8_dq[k:k + 1], transpose=True)
+            ops.fp8_quantize(w, f.w8[o:o + cnt].view(shape), f.w8_amax[k], f.w8_dq[k:k + 1])
+            ops.fp8_quantize(w, f.w8t[o:o + cnt].view(shape[1], shape[0]), f.w8_amax[k], f.w8_dq[k:k + 1], transpose=True)
 
     def _fp8_begin(self):
         """Start of a step in fp8 mode: weight mirrors, site counter, amax pools.  Activations / gradients are scaled with the amax the
@@ -329,25 +334,50 @@ class Engine:
             ws.fp8_amax[0].zero_()
             self._fp8_site = 0
 
-    def _mm(self, a, name, out, *, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None, lane=0):
+    def _fp8_alloc(self):
+        """Next GEMM-site index of the step (None outside fp8 mode).  The order of the calls is the same every step: that is what ties
+        a site to the amax it recorded one step earlier."""
+        if not self.fp8:
+            return None
+        k = self._fp8_site
+        self._fp8_site += 1
+        return k
+
+    def _emit(self, site, buf, M, N, fmt):
+        """Arguments that make a producer kernel write its [M, N] output as fp8 bytes into `buf` for GEMM site `site` (None when that is
+        not possible: no fp8 mode, first step of a workspace — no previous amax —, fusion switched off)."""
+        ws = self.ws
+        if site is None or not self.fp8 or not ws.fp8_hist or not self._fp8_fuse:
+            return None
+        return (buf[: M * N].view(M, N), fmt, ws.fp8_amax[1][site], ws.fp8_amax[0][site], ws.fp8_dq[site:site + 1])
+
+    def _mm(self, a, name, out, *, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None, lane=0, site=None, emit_site=None, a8=None):
         """out = a W^T (forward) / a W (trans_b: dX) for a block weight `name`, through the bf16 / fp32 GEMM or, in fp8 mode, through
-        quantise(a) + the fp8 GEMM.  `lane` picks the fp8 staging buffer (the two forward streams quantise concurrently)."""
+        quantise(a) + the fp8 GEMM.  `lane` picks the fp8 staging buffers (the two forward streams quantise concurrently).
+        `emit_site`: this product's output is the A operand of GEMM site `emit_site` — with delayed scaling the epilogue writes its fp8
+        copy (ws.q_b) itself; `site`: this product's A operand belongs to that pre-allocated site; `a8`: ... and its producer has
+        already left it there as fp8 bytes (the `emit` of _emit())."""
         if not self.fp8:
             return ops.gemm(a, self.W(name), out, trans_b=trans_b, bias=bias, epilogue=epilogue, aux=aux, resid=resid, st=st)
         f, ws = self.flat, self.ws
         M, K = a.shape
         o, cnt, shape = f.slots[name]
         b8 = f.w8t[o:o + cnt].view(shape[1], shape[0]) if trans_b else f.w8[o:o + cnt].view(shape)
-        k = self._fp8_site
-        self._fp8_site += 1
-        a8 = ws.a8[lane][: M * K].view(M, K)
         fmt = ops.FP8_E5M2 if trans_b else ops.FP8_E4M3
-        if ws.fp8_hist:
-            ops.fp8_quantize(a, a8, ws.fp8_amax[1][k:k + 1], ws.fp8_dq[k:k + 1], fmt=fmt, amax_next=ws.fp8_amax[0][k:k + 1], st=st)
+        prev, cur = ws.fp8_amax[1], ws.fp8_amax[0]
+        if a8 is not None:
+            k = site                                               # emitted by the producing kernel
         else:
-            ops.fp8_quantize(a, a8, ws.fp8_amax[0][k:k + 1], ws.fp8_dq[k:k + 1], fmt=fmt, st=st)
+            k = site if site is not None else self._fp8_alloc()
+            a8 = ws.a8[lane][: M * K].view(M, K)
+            if ws.fp8_hist:
+                ops.fp8_quantize(a, a8, prev[k], ws.fp8_dq[k:k + 1], fmt=fmt, amax_next=cur[k], st=st)
+            else:
+                ops.fp8_quantize(a, a8, cur[k], ws.fp8_dq[k:k + 1], fmt=fmt, st=st)
+        emit = self._emit(emit_site, ws.q_b[lane], out.shape[0], out.shape[1], fmt)   # (a forward product feeds a forward product, a dX product a dX product)
         wi = f.w8_idx[name]
-        return ops.gemm_fp8(a8, b8, out, ws.fp8_dq[k:k + 1], f.w8_dq[wi:wi + 1], a_fmt=fmt, bias=bias, epilogue=epilogue, aux=aux, resid=resid, st=st)
+        return ops.gemm_fp8(a8, b8, out, ws.fp8_dq[k:k + 1], f.w8_dq[wi:wi + 1], a_fmt=fmt, bias=bias, epilogue=epilogue, aux=aux, resid=resid,
+                            emit=emit, st=st)
 
     @staticmethod
     def _splitk(m_out, n_out, k_red, tile, ktile):
@@ -415,13 +445,22 @@ class Engine:
         stt = [a[r] for a in S["st"][i]]
         lse = S["lse"][i][b0 * H * T: (b0 + nb) * H * T]
         y1, qkv, o, y2, h, pre_a = S["y1"][i][r], S["qkv"][i][r], S["o"][i][r], S["y2"][i][r], S["h"][i][r], S["pre"][i][r]
-        ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], st=st)
-        self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=int(b0 > 0))
+        ws_q_a = self.ws.q_a if self.fp8 else None
+        ln = int(b0 > 0)
+        Mr = y1.shape[0]
+        k1 = self._fp8_alloc()
+        e1 = self._emit(k1, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
+        ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, st=st)
+        self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=ln, site=k1, a8=e1[0] if e1 else None)
         ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, st=st)
         self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0))
-        ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], st=st)
-        self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=int(b0 > 0))
-        self._mm(h, pre + "mlp.fc2.weight", x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st, lane=int(b0 > 0))
+        k2 = self._fp8_alloc()
+        e2 = self._emit(k2, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
+        ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], emit=e2, st=st)
+        kh = self._fp8_alloc()   # (fp8 mode) the site of fc2's A operand: h leaves the fc1 epilogue as bf16 AND as fp8 bytes
+        eh = self._emit(kh, self.ws.q_b[ln], Mr, 4 * Dm, 0) if self.fp8 else None
+        self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=ln, site=k2, a8=e2[0] if e2 else None, emit_site=kh)
+        self._mm(h, pre + "mlp.fc2.weight", x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st, lane=ln, site=kh, a8=eh[0] if eh else None)
 
     def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, part):
         """`lps` = the two ping-pong low-precision copies of the residual gradient; on entry and on exit lps[0] is current.  With a
@@ -439,20 +478,28 @@ class Engine:
         if not pairs:
             self._dw(cur, S["h"][i], pre + "mlp.fc2")
         self._guard_write(dpre)
-        self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st)
+        # (fp8 mode) A operands that their producer already left as fp8 bytes: `cur` (previous LayerNorm backward), dpre (the ×gelu′ epilogue)
+        kc, c8 = self._fp8_cur if self._fp8_cur is not None else (None, None)
+        self._fp8_cur = None
+        kd = self._fp8_alloc()
+        ed = self._emit(kd, ws.q_b[0], M, 4 * Dm, 1) if self.fp8 else None
+        self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
         if pairs:
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1")])
         else:
             self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
-        self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st)
+        self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
         self._guard_write(nxt)
+        kn = self._fp8_alloc()
+        en = self._emit(kn, ws.q_a[0], M, Dm, 1) if (self.fp8 and self._fp8_fuse_lnb) else None
         if dres is None:
-            ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), nxt, None, None, dres_in=cur, partial_ws=part[1], st=st)
+            ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), nxt, None, None, dres_in=cur, partial_ws=part[1], emit=en, st=st)
         else:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, None, None, dres_in=dres, dx_lp=nxt, partial_ws=part[1], st=st)
+            en = None
         if not pairs:
             self._dw(nxt, S["o"][i], pre + "attn.proj")
-        self._mm(nxt, pre + "attn.proj.weight", t1, trans_b=True, st=st)
+        self._mm(nxt, pre + "attn.proj.weight", t1, trans_b=True, st=st, site=kn, a8=en[0] if en else None)
         self._guard_write(dqkv)
         ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
         if pairs:
@@ -461,10 +508,14 @@ class Engine:
             self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
         self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st)
         self._guard_write(cur)
+        kx = self._fp8_alloc() if i > 0 else None     # the next block's fc2-backward reads `cur`
+        ex = self._emit(kx, ws.q_a[1], M, Dm, 1) if (self.fp8 and dres is None and self._fp8_fuse_lnb) else None
         if dres is None:
-            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), cur, None, None, dres_in=nxt, partial_ws=part[0], st=st)
+            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), cur, None, None, dres_in=nxt, partial_ws=part[0], emit=ex, st=st)
         else:
             ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, None, None, dres_in=dres, dx_lp=cur, partial_ws=part[0], st=st)
+        if kx is not None:
+            self._fp8_cur = (kx, ex[0] if ex else None)
 
     def _ln_flush(self, part, goff, lo, hi, M, Dm):
         """dgamma / dbeta of LayerNorms [lo, hi) of a stack (rows of `part` / `goff`): one deterministic launch."""
@@ -743,9 +794,14 @@ class Engine:
         # decoder
         lp_stream = self.res_dtype != torch.float32   # bf16 residual-gradient stream: the ping-pong buffers are the stream itself
         pd, Nd2 = ws.ln_part_d, 2 * c["Nd"]
+        self._fp8_cur = None
         if lp_stream:
+            k0 = self._fp8_alloc()
+            e0 = self._emit(k0, ws.q_a[1], ws.Md, Dd, 1) if (self.fp8 and self._fp8_fuse_lnb) else None
             ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d_lp[0], None, None,
-                              partial_ws=pd[Nd2], st=st)
+                              partial_ws=pd[Nd2], emit=e0, st=st)
+            if k0 is not None:
+                self._fp8_cur = (k0, e0[0] if e0 else None)
         else:
             ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d, None, None,
                               dx_lp=ws.dres_d_lp[0], partial_ws=pd[Nd2], st=st)
@@ -770,6 +826,7 @@ class Engine:
             ops.ntxent_bwd(ws.zc, ws.inv_norm, ws.E, ws.neg, ws.gout, ws.dpool, N, st=st)
             dpool = ws.dpool
         ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp[0], B2, Te, st=st)
+        self._fp8_cur = None
         pe, flushed = ws.ln_part_e, c["Ne"]
         for i in reversed(range(c["Ne"])):
             self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, None if lp_stream else ws.dres_e, ws.dres_e_lp, (pe[2 * i], pe[2 * i + 1]))

@@ -102,8 +102,9 @@ FP8_E4M3, FP8_E5M2 = 0, 1
 
 def fp8_quantize(src, dst, amax, dq, fmt=FP8_E4M3, transpose=False, amax_next=None, st=None):
     """dst (uint8: OCP fp8 bytes) = fp8(src * FMAX / amax), per-tensor scale on the device, `dq` receives the de-quantisation factor.
-    Current scaling (amax_next None): `amax` (1-element fp32, zeroed by the caller) first receives max|src|.  Delayed scaling: `amax` is
-    the previous step's value and is only read; this step's max|src| is folded into `amax_next` (zeroed by the caller).
+    `amax` / `amax_next` are 64-slot partial maxima (FP8_SLOTS floats, zeroed by the caller before they are written).  Current scaling
+    (amax_next None): `amax` first receives max|src|.  Delayed scaling: `amax` is the previous step's and is only read; this step's
+    max|src| is folded into `amax_next`.
     transpose: dst is [cols, rows] (weight mirror for dX)."""
     rows, cols = src.shape
     assert dst.dtype == torch.uint8 and dst.shape == ((cols, rows) if transpose else (rows, cols)) and src.stride(1) == 1 and dst.stride(1) == 1
@@ -114,8 +115,12 @@ def fp8_quantize(src, dst, amax, dq, fmt=FP8_E4M3, transpose=False, amax_next=No
                                     _p(amax_next), s), "csmae_fp8_quantize")
 
 
-def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None):
-    """out[M,N] = dq_a * dq_b * a8[M,K] b8[N,K]^T (+ epilogue): both operands K-contiguous fp8 bytes (uint8 tensors)."""
+FP8_SLOTS = 64   # an amax is 64 partial maxima (see csrc/fp8.hip)
+
+
+def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI_NONE, aux=None, resid=None, emit=None, st=None):
+    """out[M,N] = dq_a * dq_b * a8[M,K] b8[N,K]^T (+ epilogue): both operands K-contiguous fp8 bytes (uint8 tensors).
+    emit = (q_out uint8 [M,N], fmt, amax_prev [64], amax_next [64], dq [1]): the epilogue also writes `out` as fp8 bytes for the next GEMM."""
     M, K = a8.shape
     N = b8.shape[0]
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == K and out.shape == (M, N)
@@ -126,7 +131,9 @@ def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI
         _timer.begin()
     check(load().csmae_gemm_fp8(a_fmt, M, N, K, _p(a8), a8.stride(0), _p(b8), b8.stride(0), _p(out), out.stride(0), dt(out), _p(bias), epilogue,
                                 _p(aux), aux.stride(0) if aux is not None else 0, _p(resid), resid.stride(0) if resid is not None else 0,
-                                _p(dq_a), _p(dq_b), st if st is not None else stream()), "csmae_gemm_fp8")
+                                _p(dq_a), _p(dq_b), _p(emit[0]) if emit else None, emit[0].stride(0) if emit else 0, emit[1] if emit else 0,
+                                _p(emit[2]) if emit else None, _p(emit[3]) if emit else None, _p(emit[4]) if emit else None,
+                                st if st is not None else stream()), "csmae_gemm_fp8")
     if _timer is not None:
         _timer.end("gemm_fp8_NT", 2.0 * M * N * K)
     return out
@@ -170,20 +177,27 @@ def attn_bwd(qkv, out, dout, lse, dqkv, B, T, H, hd, st=None):
     check(load().csmae_attn_bwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), st if st is not None else stream()), "csmae_attn_bwd")
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, y32=None, eps=1e-6, st=None):
+def _emit_args(emit):
+    """emit = (q_out uint8, fmt, amax_prev [64], amax_next [64], dq [1]) or None -> the five trailing C arguments"""
+    if emit is None:
+        return None, 0, None, None, None
+    return _p(emit[0]), emit[1], _p(emit[2]), _p(emit[3]), _p(emit[4])
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, y32=None, eps=1e-6, emit=None, st=None):
     M, D = x.shape
-    check(load().csmae_layernorm_fwd(dt(x), dt(y), M, D, _p(x), _p(gamma), _p(beta), eps, _p(y), _p(y32), _p(mean), _p(rstd),
+    check(load().csmae_layernorm_fwd(dt(x), dt(y), M, D, _p(x), _p(gamma), _p(beta), eps, _p(y), _p(y32), _p(mean), _p(rstd), *_emit_args(emit),
                                      st if st is not None else stream()), "csmae_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx_out, dgamma, dbeta, dres_in=None, dx_lp=None, partial_ws=None, st=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx_out, dgamma, dbeta, dres_in=None, dx_lp=None, partial_ws=None, emit=None, st=None):
     """x, dres_in and dx_out share one dtype (the residual stream's).  dgamma=None with a workspace: the parameter-gradient partial
     rows stay in `partial_ws` for ln_param_reduce."""
     M, D = x.shape
     assert dx_out.dtype == x.dtype and (dres_in is None or dres_in.dtype == x.dtype)
     lp = dt(dx_lp) if dx_lp is not None else dt(dy)
     check(load().csmae_layernorm_bwd(dt(dy), dt(x), lp, M, D, _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres_in), _p(dx_out), _p(dx_lp),
-                                     _p(dgamma), _p(dbeta), _p(partial_ws), partial_ws.numel() if partial_ws is not None else 0,
+                                     _p(dgamma), _p(dbeta), _p(partial_ws), partial_ws.numel() if partial_ws is not None else 0, *_emit_args(emit),
                                      st if st is not None else stream()), "csmae_layernorm_bwd")
 
 

@@ -45,6 +45,10 @@ struct GemmArgs {
   const float* dq_a; const float* dq_b;  // fp8 kernel only: device scalars, the operands' de-quantisation factors (acc *= dq_a * dq_b)
   int a_fmt;                             // fp8 kernel only: format of A (0 = e4m3, 1 = e5m2); B is e4m3
   int aux_q8;                            // GELU / DGELU epilogues: aux (gelu') is one byte per element (GP_Q8 code below) instead of C's dtype
+  // fp8 mode, delayed scaling: the epilogue also emits its bf16 output as fp8 bytes for the GEMM that consumes it next (q_out [M][ldq]),
+  // scaled with the amax this tensor had one step earlier (q_amax_prev: 64 partial maxima), records the new amax (q_amax_next: 64 slots)
+  // and leaves the de-quantisation factor in q_dq — the separate quantisation pass (read 2 B + write 1 B per element) disappears.
+  unsigned char* q_out; long long ldq; const float* q_amax_prev; float* q_amax_next; float* q_dq; int q_fmt;
 };
 
 // gelu'(x) lies in [-0.129, 1.129]: stored as q = round((g + 0.13) * 255 / 1.26) it costs one byte instead of two in the two epilogues
@@ -218,6 +222,14 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   if (p.bias) { if (ok0) b0 = *reinterpret_cast<const f4_t*>(p.bias + gn); if (ok1) b1 = *reinterpret_cast<const f4_t*>(p.bias + gn + 4); }
   bf16_t* C = reinterpret_cast<bf16_t*>(Cptr);
   bf16_t* X = reinterpret_cast<bf16_t*>(p.aux);
+  const bool emit = p.q_out != nullptr;
+  const float qmax = p.q_fmt == 0 ? 448.0f : 57344.0f;
+  float qscale = 1.f, qseen = 0.f;
+  if (emit) {
+    const float am = wave_max(p.q_amax_prev[lane]);
+    qscale = am > 0.f ? qmax / am : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.q_dq[0] = am > 0.f ? am / qmax : 1.f;
+  }
   const bf16_t* LS = EPI == EPI_RESID ? reinterpret_cast<const bf16_t*>(p.resid) : X;   // what the phase loads: bf16 residual stream / gelu'
   const long long lds_ = EPI == EPI_RESID ? p.ldr : p.ldaux;
   uint4 ld[NEEDS_LOAD ? NPASS : 1];
@@ -258,6 +270,25 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
         if (EPI == EPI_DGELU && p.aux_q8) { a0 = gp_q8_unpack4(a.x); a1 = gp_q8_unpack4(a.y); }
         if (EPI == EPI_DGELU) { o0 = v0 * a0; o1 = v1 * a1; } else { o0 = v0 + a0; o1 = v1 + a1; }
       }
+      if (emit && gm < p.M && ok0) {   // the fp8 copy of this row segment (8 or 4 columns)
+        f4_t q0 = o0 * qscale, q1 = o1 * qscale;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          qseen = fmaxf(qseen, fmaxf(fabsf(o0[k]), ok1 ? fabsf(o1[k]) : 0.f));
+          q0[k] = fminf(fmaxf(q0[k], -qmax), qmax); q1[k] = fminf(fmaxf(q1[k], -qmax), qmax);
+        }
+        int w0 = 0, w1 = 0;
+        if (p.q_fmt == 0) {
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q0[0], q0[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q0[2], q0[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q1[0], q1[1], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q1[2], q1[3], w1, true);
+        } else {
+          w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q0[0], q0[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q0[2], q0[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q1[0], q1[1], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q1[2], q1[3], w1, true);
+        }
+        unsigned char* qd = p.q_out + (long long)gm * p.ldq + gn;
+        if (ok1) *reinterpret_cast<uint2*>(qd) = make_uint2((unsigned)w0, (unsigned)w1);
+        else *reinterpret_cast<unsigned*>(qd) = (unsigned)w0;
+      }
       if (gm < p.M) {
         if (EPI == EPI_GELU && p.aux_q8) {
           unsigned char* d8 = reinterpret_cast<unsigned char*>(p.aux) + (long long)gm * p.ldaux + gn;
@@ -273,6 +304,10 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
         }
       }
     }
+  }
+  if (emit) {   // this wave's share of the new amax: one atomic per wave, spread over the 64 slots
+    qseen = wave_max(qseen);
+    if (lane == 0 && qseen > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q_amax_next) + ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 63), __float_as_uint(qseen));
   }
 }
 
@@ -845,7 +880,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
   p.M = d.M; p.N = d.N; p.K = ga.K;
   p.c_dtype = CSMAE_F32; p.epi = EPI_RESID; p.splitk = ga.nsplit; p.tiles_m = 0; p.tiles_n = d.tiles_n; p.ktiles = ga.ktiles; p.ktiles_per_split = ga.ktiles_per_split;
   p.a_bytes = (unsigned)((long long)ga.K * d.ldy * 2); p.b_bytes = (unsigned)((long long)ga.K * d.ldx * 2);
-  p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = 0;
+  p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = 0; p.q_out = nullptr;
   k64_tile<true, true, 256, true>(p, tm, tn, split, kt_begin, kt_end, DwFold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles});
 }
 // fold of the K slices of a grouped launch: workgroup (tile, part) adds the tile's slabs in slice order and accumulates 16 rows into
@@ -980,7 +1015,8 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_kernel(GemmArgs p) {
 
 extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb,
                               void* C, long long ldc, int c_dtype, const float* bias, int epilogue, void* aux, long long ldaux,
-                              const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* stream) {
+                              const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* q_out, long long ldq, int q_fmt,
+                              const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && ldc % 4 == 0, "csmae_gemm_fp8: bad geometry M=%lld N=%lld K=%lld", M, N, K);
   CSMAE_REQUIRE(a_fmt == 0 || a_fmt == 1, "csmae_gemm_fp8: a_fmt 0 (e4m3) or 1 (e5m2)");
   const int q8 = (epilogue == 6 || epilogue == 7);
@@ -1000,6 +1036,12 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
   p.ktiles = cdiv(K, 128); p.ktiles_per_split = p.ktiles;
   p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
   p.dq_a = dq_a; p.dq_b = dq_b; p.a_fmt = a_fmt; p.aux_q8 = q8;
+  p.q_out = reinterpret_cast<unsigned char*>(q_out); p.ldq = ldq; p.q_fmt = q_fmt; p.q_amax_prev = q_amax_prev; p.q_amax_next = q_amax_next; p.q_dq = q_dq;
+  if (q_out) {   // (the fp8 copy leaves through the 16-byte-row epilogue only)
+    const bool wide = (ldc % 8 == 0) && (epilogue == EPI_NONE || (epilogue == EPI_RESID ? (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0) : (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)));
+    CSMAE_REQUIRE(c_dtype == CSMAE_BF16 && wide && ldq % 8 == 0 && ((uintptr_t)q_out & 7) == 0 && q_amax_prev && q_amax_next && q_dq && (q_fmt == 0 || q_fmt == 1),
+                  "csmae_gemm_fp8: the fused fp8 copy needs a bf16 output with 8-element aligned rows and the three scale pointers");
+  }
   dim3 grid(p.tiles_m * p.tiles_n);
   if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(gemm_fp8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
@@ -1080,7 +1122,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
   p.force_cfg = g_force_cfg;
   p.split_stride = M * ldc;
   p.colsum = (epilogue == EPI_SPLIT && transA && transB && dtype == CSMAE_BF16) ? reinterpret_cast<float*>(aux) : nullptr;
-  p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = q8;
+  p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = q8; p.q_out = nullptr;
   p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;

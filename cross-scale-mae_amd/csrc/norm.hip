@@ -3,42 +3,70 @@
 // (wave-shuffle reductions, 16-B accesses), one workgroup per BatchNorm channel.
 #include "common.h"
 
+// fp8 mode, delayed scaling (csrc/fp8.hip, csmae_gemm_fp8): a kernel that produces a GEMM's A operand also writes it as fp8 bytes, scaled
+// with the amax the tensor had one step earlier (64 partial maxima), and records the new amax — no separate quantisation pass.
+struct Fp8Emit { unsigned char* q; const float* amax_prev; float* amax_next; float* dq; int fmt; };
+__device__ __forceinline__ float fp8_emit_scale(const Fp8Emit& e, int lane, float& qmax) {
+  qmax = e.fmt == 0 ? 448.0f : 57344.0f;
+  const float am = wave_max(e.amax_prev[lane & 63]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) e.dq[0] = am > 0.f ? am / qmax : 1.f;
+  return am > 0.f ? qmax / am : 1.f;
+}
+__device__ __forceinline__ unsigned fp8_pack4(f4_t v, float scale, float qmax, int fmt, float& seen) {
+  int p = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { seen = fmaxf(seen, fabsf(v[k])); v[k] = fminf(fmaxf(v[k] * scale, -qmax), qmax); }
+  if (fmt == 0) { p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true); }
+  else { p = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], p, true); }
+  return (unsigned)p;
+}
+__device__ __forceinline__ void fp8_emit_amax(const Fp8Emit& e, float seen, int lane) {
+  seen = wave_max(seen);
+  if (lane == 0 && seen > 0.f) atomicMax(reinterpret_cast<unsigned*>(e.amax_next) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(seen));
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm forward
 template <typename TX, typename TO, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const TX* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, TO* __restrict__ y, float* __restrict__ y32,
-                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd, Fp8Emit em) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  float qmax = 0.f, qseen = 0.f;
+  const float qscale = em.q ? fp8_emit_scale(em, lane, qmax) : 1.f;
   const int nv = D >> 2;
-  f4_t v[NV];
-  float s = 0.f;
+  // one row per wave and pass; the grid covers all rows in one pass unless an fp8 copy is emitted: then a wave walks several rows, so that
+  // reading the scale (a dependent global load + wave reduction) and the amax atomic are paid once per wave, not once per row
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (long long)gridDim.x * 4) {
+    f4_t v[NV];
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int c = lane + i * 64;
-    v[i] = c < nv ? ld4<TX>(x + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
-    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-  }
-  const float mu = wave_sum(s) / D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int c = lane + i * 64;
-    if (c < nv) { f4_t d = v[i] - mu; q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]; }
-  }
-  const float rs = rsqrtf(wave_sum(q) / D + eps);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int c = lane + i * 64;
-    if (c < nv) {
-      f4_t gm = *reinterpret_cast<const f4_t*>(gamma + c * 4), bt = *reinterpret_cast<const f4_t*>(beta + c * 4);
-      f4_t o = (v[i] - mu) * rs * gm + bt;
-      st4<TO>(y + row * D + c * 4, o);
-      if (y32) *reinterpret_cast<f4_t*>(y32 + row * D + c * 4) = o;
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + i * 64;
+      v[i] = c < nv ? ld4<TX>(x + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + i * 64;
+      if (c < nv) { f4_t d = v[i] - mu; q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]; }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = lane + i * 64;
+      if (c < nv) {
+        f4_t gm = *reinterpret_cast<const f4_t*>(gamma + c * 4), bt = *reinterpret_cast<const f4_t*>(beta + c * 4);
+        f4_t o = (v[i] - mu) * rs * gm + bt;
+        st4<TO>(y + row * D + c * 4, o);
+        if (y32) *reinterpret_cast<f4_t*>(y32 + row * D + c * 4) = o;
+        if (em.q) *reinterpret_cast<unsigned*>(em.q + row * D + c * 4) = fp8_pack4(o, qscale, qmax, em.fmt, qseen);
+      }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   }
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  if (em.q) fp8_emit_amax(em, qseen, lane);
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm backward
@@ -50,9 +78,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const TX* __restrict__ dres_in,
                                                      TX* __restrict__ dx_out, TLP* __restrict__ dx_lp,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part, Fp8Emit em) {
   __shared__ float red[4 * 64 * 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float qmax = 0.f, qseen = 0.f;
+  const float qscale = em.q ? fp8_emit_scale(em, lane, qmax) : 1.f;
   const int nv = D >> 2;
   f4_t gm[NV], ag[NV], ab[NV];
 #pragma unroll
@@ -93,9 +123,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const T
         f4_t dx = (g[i] - s1 - xh[i] * s2) * rs + dr[i];
         st4<TX>(dx_out + row * D + c * 4, dx);
         if (dx_lp) st4<TLP>(dx_lp + row * D + c * 4, dx);
+        if (em.q) *reinterpret_cast<unsigned*>(em.q + row * D + c * 4) = fp8_pack4(dx, qscale, qmax, em.fmt, qseen);
       }
     }
   }
+  if (em.q) fp8_emit_amax(em, qseen, lane);
   if (!dgamma && !part) return;
   // fold the 4 waves' column partials into this block's partial row (or, without a workspace, one atomic per column per block)
 #pragma unroll
@@ -158,22 +190,29 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(int nblk, int D, 
 }
 
 template <typename TX, typename TO>
-static int ln_fwd_launch(long long M, int D, const void* x, const float* g, const float* b, float eps, void* y, float* y32, float* mean, float* rstd, hipStream_t st) {
-  dim3 grid(cdiv(M, 4)), block(256);
+static int ln_fwd_launch(long long M, int D, const void* x, const float* g, const float* b, float eps, void* y, float* y32, float* mean, float* rstd, Fp8Emit em, hipStream_t st) {
+  dim3 grid(em.q ? (unsigned)fmin((double)cdiv(M, 4), 2048.0) : (unsigned)cdiv(M, 4)), block(256);
   int nv = cdiv(D, 256);
-#define LNF(NVV) hipLaunchKernelGGL((ln_fwd_kernel<TX, TO, NVV>), grid, block, 0, st, M, D, (const TX*)x, g, b, eps, (TO*)y, y32, mean, rstd)
+#define LNF(NVV) hipLaunchKernelGGL((ln_fwd_kernel<TX, TO, NVV>), grid, block, 0, st, M, D, (const TX*)x, g, b, eps, (TO*)y, y32, mean, rstd, em)
   switch (nv) { case 1: LNF(1); break; case 2: LNF(2); break; case 3: LNF(3); break; case 4: LNF(4); break; case 5: LNF(5); break; default: LNF(8); }
 #undef LNF
   return CSMAE_OK;
 }
 
+static int fp8_emit_check(const char* who, void* q, int fmt, const float* prev, float* next, float* dq) {
+  CSMAE_REQUIRE(!q || (prev && next && dq && (fmt == 0 || fmt == 1) && ((uintptr_t)q & 3) == 0), "%s: the fused fp8 copy needs amax_prev, amax_next, dq and fmt 0 / 1", who);
+  return CSMAE_OK;
+}
 extern "C" int csmae_layernorm_fwd(int x_dtype, int out_dtype, long long M, int D, const void* x, const float* gamma, const float* beta, float eps,
-                                   void* y, float* y32, float* mean, float* rstd, void* stream) {
+                                   void* y, float* y32, float* mean, float* rstd, void* q_out, int q_fmt, const float* q_amax_prev,
+                                   float* q_amax_next, float* q_dq, void* stream) {
   CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_fwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  if (int rc = fp8_emit_check("csmae_layernorm_fwd", q_out, q_fmt, q_amax_prev, q_amax_next, q_dq)) return rc;
+  const Fp8Emit em{(unsigned char*)q_out, q_amax_prev, q_amax_next, q_dq, q_fmt};
   hipStream_t st = (hipStream_t)stream;
-  if (x_dtype == CSMAE_F32 && out_dtype == CSMAE_BF16) ln_fwd_launch<float, bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, st);
-  else if (x_dtype == CSMAE_F32 && out_dtype == CSMAE_F32) ln_fwd_launch<float, float>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, st);
-  else if (x_dtype == CSMAE_BF16 && out_dtype == CSMAE_BF16) ln_fwd_launch<bf16_t, bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, st);
+  if (x_dtype == CSMAE_F32 && out_dtype == CSMAE_BF16) ln_fwd_launch<float, bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, em, st);
+  else if (x_dtype == CSMAE_F32 && out_dtype == CSMAE_F32) ln_fwd_launch<float, float>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, em, st);
+  else if (x_dtype == CSMAE_BF16 && out_dtype == CSMAE_BF16) ln_fwd_launch<bf16_t, bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, em, st);
   else { csmae_set_error("csmae_layernorm_fwd: bad dtypes %d -> %d", x_dtype, out_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_layernorm_fwd");
 }
@@ -188,7 +227,7 @@ static int ln_bwd_blocks(long long M, int D, long long part_elems) {
 template <typename TDY, typename TX, typename TLP>
 static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                           const void* dres_in, void* dx_out, void* dx_lp, float* dgamma, float* dbeta, float* part, long long part_elems,
-                          hipStream_t st) {
+                          Fp8Emit em, hipStream_t st) {
   int blocks = (int)fmin((double)cdiv(M, 4), 1024.0);
   if (part) {
     blocks = ln_bwd_blocks(M, D, part_elems);
@@ -196,7 +235,7 @@ static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, con
   }
   dim3 grid(blocks), block(256);
   int nv = cdiv(D, 256);
-#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, (const TX*)dres_in, (TX*)dx_out, (TLP*)dx_lp, dgamma, dbeta, part)
+#define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, (const TX*)dres_in, (TX*)dx_out, (TLP*)dx_lp, dgamma, dbeta, part, em)
   switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break; case 5: LNB(5); break; default: LNB(8); }
 #undef LNB
   if (part && dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), 1), dim3(1024), 0, st, blocks, D, part, 0ll, (float*)nullptr, (const long long*)nullptr, dgamma, dbeta);
@@ -204,11 +243,14 @@ static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, con
 
 extern "C" int csmae_layernorm_bwd(int dy_dtype, int x_dtype, int lp_dtype, long long M, int D, const void* dy, const void* x, const float* mean,
                                    const float* rstd, const float* gamma, const void* dres_in, void* dx_out, void* dx_lp,
-                                   float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* stream) {
+                                   float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* q_out, int q_fmt,
+                                   const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream) {
   CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_bwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
+  if (int rc = fp8_emit_check("csmae_layernorm_bwd", q_out, q_fmt, q_amax_prev, q_amax_next, q_dq)) return rc;
+  const Fp8Emit em{(unsigned char*)q_out, q_amax_prev, q_amax_next, q_dq, q_fmt};
   CSMAE_REQUIRE(dgamma || !partial_ws || partial_elems >= 2ll * D, "csmae_layernorm_bwd: deferred parameter gradients need a workspace of at least one partial row");
   hipStream_t st = (hipStream_t)stream;
-#define GO(A, X, L) ln_bwd_launch<A, X, L>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, st)
+#define GO(A, X, L) ln_bwd_launch<A, X, L>(M, D, dy, x, mean, rstd, gamma, dres_in, dx_out, dx_lp, dgamma, dbeta, partial_ws, partial_elems, em, st)
   if (x_dtype == CSMAE_BF16) {       // bf16 residual streams (throughput mode): dx_out is the GEMM operand itself
     if (dy_dtype == CSMAE_BF16) GO(bf16_t, bf16_t, bf16_t);
     else if (dy_dtype == CSMAE_F32) GO(float, bf16_t, bf16_t);

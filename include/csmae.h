@@ -58,7 +58,8 @@ int csmae_gemm_dw_group(int dtype, int count, long long K, const void* const* dY
                         const long long* ldx, float* const* dW, float* const* db, const long long* M, const long long* N, int slots,
                         float* workspace, long long ws_elems, void* stream);
 /* ---- fp8 MFMA path (BASELINE.json configs[4]: "fp8 MFMA GEMMs"; the same nn.Linear call sites, MAE_ViT_Baseline.py:160-188).
- * OCP fp8, per-tensor scales: csmae_fp8_amax folds max|x| into a device scalar the caller zeroed; csmae_fp8_quantize writes
+ * OCP fp8, per-tensor scales.  An amax is 64 partial maxima (float[64]; its value is their maximum: thousands of same-address atomics per
+ * launch serialise in L2): csmae_fp8_amax folds max|x| into slots the caller zeroed; csmae_fp8_quantize writes
  * q = fp8(x * FMAX / amax) (fmt 0 = e4m3, 1 = e5m2; transpose = 1 writes dst[c][r], the mirror of a weight the dX products read) and
  * the de-quantisation factor dq = amax / FMAX; with amax_next the amax passed in is the previous step's (one pass over the tensor,
  * out-of-range values saturate) and this step's is recorded for the next.  csmae_gemm_fp8: C[M,N] = dq_a * dq_b * sum_k A8(m,k) B8(n,k) with both operands
@@ -68,7 +69,9 @@ int csmae_fp8_quantize(int in_dtype, int fmt, int transpose, long long rows, int
                        long long ldd, const float* amax, float* dq, float* amax_next /* nullable: delayed scaling, += max|src| */, void* stream);
 int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb,
                    void* C, long long ldc, int c_dtype, const float* bias, int epilogue, void* aux, long long ldaux,
-                   const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* stream);
+                   const void* resid, long long ldr, const float* dq_a, const float* dq_b,
+                   void* q_out /* nullable: also emit C as fp8 bytes [M][ldq] in q_fmt for the GEMM that reads it next (delayed scaling) */,
+                   long long ldq, int q_fmt, const float* q_amax_prev /* [64] */, float* q_amax_next /* [64] */, float* q_dq, void* stream);
 /* tuning hook for tools/gemm_bench.py: force the bf16 block tile (0: 128x128, 1: 256x128, 2: 256x256, -1: heuristic) */
 int csmae_gemm_force_tile(int cfg);
 
@@ -83,12 +86,16 @@ int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv
  * bwd: dx_out = dres_in + LN'(dy), both in x_dtype (the residual-gradient stream); dx_lp = optional low-precision copy for the next
  * GEMM (with a bf16 stream dx_out is that operand); dgamma/dbeta += via per-block partial rows in partial_ws (>= 2*D floats per
  * block; null -> atomics).  dgamma == NULL with a workspace: the partial rows (min(ceil(M/4), 1024, partial_elems / 2D) of them) are
- * left there for csmae_ln_param_reduce, which folds a whole batch of LayerNorms in one launch off the critical path. */
+ * left there for csmae_ln_param_reduce, which folds a whole batch of LayerNorms in one launch off the critical path.
+ * q_out (nullable; fp8 mode, delayed scaling): the output that feeds the next GEMM (y / dx_out) also leaves as fp8 bytes [M][D] in q_fmt,
+ * scaled with q_amax_prev (64 partial maxima), the new amax folded into q_amax_next (64 slots), the de-quantisation factor in q_dq. */
 int csmae_layernorm_fwd(int x_dtype, int out_dtype, long long M, int D, const void* x, const float* gamma, const float* beta, float eps,
-                        void* y, float* y32, float* mean, float* rstd, void* stream);
+                        void* y, float* y32, float* mean, float* rstd, void* q_out, int q_fmt, const float* q_amax_prev,
+                        float* q_amax_next, float* q_dq, void* stream);
 int csmae_layernorm_bwd(int dy_dtype, int x_dtype, int lp_dtype, long long M, int D, const void* dy, const void* x, const float* mean,
                         const float* rstd, const float* gamma, const void* dres_in, void* dx_out, void* dx_lp,
-                        float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* stream);
+                        float* dgamma, float* dbeta, float* partial_ws, long long partial_elems, void* q_out, int q_fmt,
+                        const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream);
 /* LayerNorm k of the batch: partial rows at partials + k * stride (slice_elems floats each, written by csmae_layernorm_bwd with the same
  * M and D), dgamma at gbase + goff[2k], dbeta at gbase + goff[2k+1] (device array).  Fixed summation order, no atomics. */
 int csmae_ln_param_reduce(int count, long long M, int D, const float* partials, long long stride, long long slice_elems,

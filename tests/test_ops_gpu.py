@@ -174,10 +174,10 @@ def test_fp8_quantize_matches_torch_float8(ops, fmt, src_dtype):
         x = (rnd(rows, cols, seed=70) * 3.0).to(src_dtype)
         x[3, 5] = 17.5   # the maximum
         q = torch.empty(rows, cols, device="cuda", dtype=torch.uint8)
-        amax, dq = torch.zeros(1, device="cuda"), torch.empty(1, device="cuda")
+        amax, dq = torch.zeros(64, device="cuda"), torch.empty(1, device="cuda")   # an amax = 64 partial maxima
         ops.fp8_quantize(dev(x), q, amax, dq, fmt=fmt)
         am = x.float().abs().max()
-        assert float(amax) == float(am) and abs(float(dq) - float(am) / fmax) <= 1e-6 * float(am) / fmax
+        assert float(amax.max()) == float(am) and abs(float(dq) - float(am) / fmax) <= 1e-6 * float(am) / fmax
         scale = torch.tensor(fmax, dtype=torch.float32) / am
         want = (x.float() * scale).clamp(-fmax, fmax).to(tdt).view(torch.uint8)
         assert torch.equal(q.cpu(), want), (fmt, rows, cols, int((q.cpu() != want).sum()))
@@ -199,7 +199,8 @@ def test_gemm_fp8_vs_fp32_on_the_quantised_operands(ops, a_fmt):
         w = rnd(N, K, seed=81) * 0.05 + torch.arange(N)[:, None] / (8.0 * N)
         a8 = torch.empty(M, K, device="cuda", dtype=torch.uint8)
         w8 = torch.empty(N, K, device="cuda", dtype=torch.uint8)
-        am, dqa, wm, dqw = (torch.zeros(1, device="cuda") for _ in range(4))
+        am, wm = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+        dqa, dqw = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
         ops.fp8_quantize(dev(a.to(torch.bfloat16)), a8, am, dqa, fmt=a_fmt)
         ops.fp8_quantize(dev(w), w8, wm, dqw, fmt=0)
         ad = a8.view(adt).float().cpu() * float(dqa)
@@ -220,6 +221,21 @@ def test_gemm_fp8_vs_fp32_on_the_quantised_operands(ops, a_fmt):
         assert_close(outb, torch.nn.functional.gelu(pre), 1e-2, 1e-2 * scale, "fp8 gemm + gelu")
         ops.gemm_fp8(a8, w8, outb, dqa, dqw, a_fmt=a_fmt, epilogue=EPI_DGELU, aux=aux)
         assert_close(outb, ref.float() * aux.float().cpu(), 1e-2, 1e-2 * scale, "fp8 gemm x gelu'")
+        # delayed scaling fused into the epilogue: the output also leaves as fp8 bytes, scaled with a GIVEN (previous-step) amax, and
+        # this step's amax is recorded — what the separate quantisation pass of the consuming GEMM would have produced
+        prev = torch.zeros(64, device="cuda"); prev[17] = 0.8 * float(outb.float().abs().max())   # (smaller than today's: saturation path)
+        nxt, dqo = torch.zeros(64, device="cuda"), torch.zeros(1, device="cuda")
+        q = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+        out2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        efmt, edt, fmax = (0, torch.float8_e4m3fn, 448.0) if a_fmt == 0 else (1, torch.float8_e5m2, 57344.0)
+        ops.gemm_fp8(a8, w8, out2, dqa, dqw, a_fmt=a_fmt, epilogue=EPI_DGELU, aux=aux, emit=(q, efmt, prev, nxt, dqo))
+        assert torch.equal(out2, outb)
+        assert abs(float(dqo) - float(prev.max()) / fmax) <= 1e-6 * float(dqo)
+        assert abs(float(nxt.max()) - float(out2.float().abs().max())) <= 8e-3 * float(nxt.max())      # (recorded before the bf16 rounding)
+        deq = q.view(edt).float().cpu() * float(dqo)
+        want = out2.float().cpu().clamp(-float(prev.max()), float(prev.max()))
+        tol = (0.0625 if a_fmt == 0 else 0.125) * want.abs() + float(prev.max()) * (2.0 ** -9 if a_fmt == 0 else 2.0 ** -16) + 8e-3 * want.abs()
+        assert bool(((deq - want).abs() <= tol).all()), float(((deq - want).abs() - tol).max())
 
 
 def test_gemm_rejects_bad_args(ops):
@@ -336,6 +352,42 @@ def test_layernorm_bf16_residual_stream_and_deferred_param_grads(ops, MD):
         touched[goff[k, 0]: goff[k, 0] + D] = True
         touched[goff[k, 1]: goff[k, 1] + D] = True
     assert bool((flatg[~touched] == 1.0).all())
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_layernorm_emits_fp8_copy(ops, fmt):
+    """fp8 mode, delayed scaling: LayerNorm forward / backward leave the tensor the next GEMM reads as fp8 bytes too, scaled with a given
+    (previous-step) amax; the new amax is recorded.  The bf16 outputs are unchanged by the emission."""
+    M, D = 200, 512
+    edt, fmax = (torch.float8_e4m3fn, 448.0) if fmt == 0 else (torch.float8_e5m2, 57344.0)
+    x = (rnd(M, D, seed=30, scale=2.0) + 0.5).to(torch.bfloat16)
+    g, b = rnd(D, seed=31) * 0.2 + 1.0, rnd(D, seed=32) * 0.1
+    y, y2 = torch.empty(M, D, device="cuda", dtype=torch.bfloat16), torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), y, mean, rstd)
+    prev = torch.zeros(64, device="cuda"); prev[5] = 0.9 * float(y.float().abs().max())
+    nxt, dq = torch.zeros(64, device="cuda"), torch.zeros(1, device="cuda")
+    q = torch.empty(M, D, device="cuda", dtype=torch.uint8)
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), y2, mean, rstd, emit=(q, fmt, prev, nxt, dq))
+    assert torch.equal(y, y2)
+    am = float(prev.max())
+    assert abs(float(dq) - am / fmax) <= 1e-6 * am / fmax and abs(float(nxt.max()) - float(y.float().abs().max())) <= 8e-3 * float(nxt.max())
+    deq = q.view(edt).float().cpu() * float(dq)
+    want = y.float().cpu().clamp(-am, am)
+    tol = (0.0625 if fmt == 0 else 0.125) * want.abs() + am * (2.0 ** -9 if fmt == 0 else 2.0 ** -16) + 8e-3 * want.abs()
+    assert bool(((deq - want).abs() <= tol).all())
+    dy, dres = rnd(M, D, seed=33).to(torch.bfloat16), rnd(M, D, seed=34).to(torch.bfloat16)
+    dx, dx2 = torch.empty(M, D, device="cuda", dtype=torch.bfloat16), torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    part = torch.empty(1024 * 2 * D, device="cuda")
+    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dx, None, None, dres_in=dev(dres), partial_ws=part)
+    prev.zero_(); prev[40] = 1.1 * float(dx.float().abs().max()); nxt.zero_()
+    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dx2, None, None, dres_in=dev(dres), partial_ws=part, emit=(q, fmt, prev, nxt, dq))
+    assert torch.equal(dx, dx2)
+    am = float(prev.max())
+    deq = q.view(edt).float().cpu() * float(dq)
+    want = dx.float().cpu()
+    tol = (0.0625 if fmt == 0 else 0.125) * want.abs() + am * (2.0 ** -9 if fmt == 0 else 2.0 ** -16) + 8e-3 * want.abs()
+    assert bool(((deq - want).abs() <= tol).all()) and abs(float(nxt.max()) - float(want.abs().max())) <= 8e-3 * float(nxt.max())
 
 
 def test_gemm_residual_epilogue_bf16_stream(ops):
