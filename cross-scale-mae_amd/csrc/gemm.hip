@@ -538,7 +538,7 @@ extern "C" int csmae_debug_gemm_ts(unsigned long long* out) { return (int)hipMem
 #define GTS(i)
 #endif
 // main-loop ablations of the pipelined kernel, compile-time only (tools/gemm_ablate.sh builds variant libraries; never in the product build):
-// -DGEMM_ABL=1 no fragment reads | 2 no DMA pieces | 4 no MFMAs | 8 no bias-gradient sums
+// -DGEMM_ABL=1 no fragment reads | 2 no DMA pieces | 4 no MFMAs | 8 no bias-gradient sums | 16 MFMA rows at raised s_setprio (measured: no gain)
 #ifndef GEMM_ABL
 #define GEMM_ABL 0
 #endif
@@ -677,9 +677,11 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   float cs[2] = {0.f, 0.f};
   auto mma_row = [&](int i, const s8_t& fa, const s8_t (&fb)[FN]) {
     if (!(GEMM_ABL & 4)) {
+      if (GEMM_ABL & 16) __builtin_amdgcn_s_setprio(2);   // (experiment: MFMA rows at raised priority)
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[j]), __builtin_bit_cast(bf8_t, fa), acc[i][j], 0, 0, 0);
+      if (GEMM_ABL & 16) __builtin_amdgcn_s_setprio(0);
     }
     if (TA && TB && !(GEMM_ABL & 8) && do_cs && wq == (i >> 1)) {
       const u4_t d = __builtin_bit_cast(u4_t, fa);
