@@ -201,7 +201,7 @@ def main():
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["work"] for v in summ.values())
         kernel = dict(name="GEMM family: gemm_bf16_k64_kernel + gemm_dw_group_kernel (MFMA 16x16x32 bf16)" + (" + gemm_fp8_kernel (MFMA 16x16x128 f8f6f4)" if a.dtype == "fp8" else "") +
-                      "; serialised on one stream for the HIP-event timing", launches_per_step=sum(v["launches"] for v in summ.values()),
+                      "; serialised on one stream for the HIP-event timing (every launch alone on the chip; in the overlapped step the weight-gradient launches are held to 160 workgroups)", launches_per_step=sum(v["launches"] for v in summ.values()),
                       ms_per_step=round(tot_ms, 3), tflops=round(tot_fl / tot_ms / 1e9, 1),
                       by_layout={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=round(v["work"] / v["ms"] / 1e9, 1)) for k, v in summ.items()})
     # HBM bytes per GEMM launch from the committed PMC passes (counters cannot be read from inside this process).  The profile names the
