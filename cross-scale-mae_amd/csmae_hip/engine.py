@@ -813,9 +813,9 @@ class Engine:
         self._dw(ws.dz_lp, lat_op, "decoder_embed")
         ops.gemm(ws.dz_lp, self.W("decoder_embed.weight"), ws.dres_e, trans_b=True, st=st)
         dp = getattr(self.module, "_dp", None)
-        if dp is not None:
-            self._join_side()
-            dp.grads_ready(self.flat, "tail")  # decoder + heads are final: their all-reduce overlaps the encoder backward
+        if dp is not None:   # decoder + heads are final: their all-reduce overlaps the encoder backward.  The exchange stream waits for
+            # the weight-gradient stream itself (`also`): the main chain does not stop for the block's grouped launches to finish
+            dp.grads_ready(self.flat, "tail", also=self.side if not (ops._timer is not None or os.environ.get("CSMAE_DW_MAIN")) else None)
         latent = ws.lat32 if ws.lat32 is not None else ws.enc["x"][c["Ne"]]
         if self.has_le:
             ke = c["loss_e"]
@@ -833,8 +833,7 @@ class Engine:
             if dp is not None and dp.wants(("enc", i)):
                 self._ln_flush(pe, self._goff_e, 2 * i, 2 * flushed, ws.Me, D)   # the bucket's LayerNorm gradients must be final before its exchange
                 flushed = i
-                self._join_side()
-                dp.grads_ready(self.flat, ("enc", i))
+                dp.grads_ready(self.flat, ("enc", i), also=self.side if not (ops._timer is not None or os.environ.get("CSMAE_DW_MAIN")) else None)
         self._ln_flush(pe, self._goff_e, 0, 2 * flushed, ws.Me, D)
         ops.embed_assemble_bwd(ws.dres_e_lp[0] if lp_stream else ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
         self._join_side()

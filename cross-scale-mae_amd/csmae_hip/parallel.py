@@ -37,15 +37,18 @@ class GradSync:
         # gloo has no AVG; RCCL does
         self._avg = self.cuda and is_dist() and dist.get_backend(group) == "nccl"
 
-    def reduce_range(self, lo: int, hi: int):
+    def reduce_range(self, lo: int, hi: int, also=None):
         """Enqueue mean-all-reduce of g[lo:hi].  On GPU it runs on the side stream after everything already enqueued on the
-        current stream (the kernels that produced g[lo:hi])."""
+        current stream and on `also` (the engine's weight-gradient stream): the kernels that produced g[lo:hi].  The producers' streams
+        are not made to wait for each other — only the exchange waits."""
         if (self.world == 1 and not self.force) or hi <= lo:
             return
         self.issued.append((lo, hi))
         seg = self.g[lo:hi]
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
+            if also is not None:
+                self.stream.wait_stream(also)
             with torch.cuda.stream(self.stream):
                 self._reduce(seg, lo, hi)
             self._pending = True
@@ -178,12 +181,12 @@ class DataParallel(torch.nn.Module):
             self._sync.broadcast([fb.raw])
 
     # called by Engine.backward
-    def grads_ready(self, flat, name):
+    def grads_ready(self, flat, name, also=None):
         if not self.require_backward_grad_sync or not is_dist():
             return
         sync = self._ensure(flat)
         if name in self._ranges:
-            sync.reduce_range(*self._ranges[name])
+            sync.reduce_range(*self._ranges[name], also=also)
 
     def wants(self, name) -> bool:
         """True if `name` closes a bucket (lets the engine skip joining its weight-gradient stream otherwise)."""
