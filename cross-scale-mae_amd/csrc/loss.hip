@@ -27,14 +27,16 @@ __device__ __forceinline__ float elem_grad(int kind, float pred, float t) {  // 
 __device__ __forceinline__ bool mean_over_last(int kind) { return kind == LOSS_MSE || kind == LOSS_MAE || kind == LOSS_BCE; }
 
 // one wave per patch: target values of patch (n2, l); element e = (ph*p + pw)*C + c   (MAE_ViT_Shared.py:36-38 "nhwpqc")
-struct PatchGeom { int N, C, S, p, L, G, P; };
+struct PatchGeom { int N, C, S, p, L, G, P; unsigned mC, mp; };   // mC / mp: ceil(2^24 / C), ceil(2^24 / p) — n / d = (n * m) >> 24 for n * d < 2^24 (0: divide)
 __device__ __forceinline__ const float* patch_img(const PatchGeom& g, const float* img0, const float* img1, long long n2) {
   int view = (int)(n2 / g.N);
   return (view ? img1 : img0) + (n2 - (long long)view * g.N) * g.C * g.S * g.S;
 }
 __device__ __forceinline__ float patch_elem(const PatchGeom& g, const float* img, int l, int e) {
   int gh = l / g.G, gw = l - gh * g.G;
-  int c = e % g.C, r = e / g.C, ph = r / g.p, pw = r - ph * g.p;
+  // (three integer divisions per element were most of this loop: exact multiply-shift instead when the operands allow it)
+  const int r = g.mC ? (int)(((unsigned long long)(unsigned)e * g.mC) >> 24) : e / g.C, c = e - r * g.C;
+  const int ph = g.mp ? (int)(((unsigned long long)(unsigned)r * g.mp) >> 24) : r / g.p, pw = r - ph * g.p;
   return img[((long long)c * g.S + gh * g.p + ph) * g.S + gw * g.p + pw];
 }
 // per-patch normalisation statistics (norm_pix_loss: unbiased variance, eps 1e-6 — MAE_ViT_Shared.py:106-109)
@@ -135,7 +137,12 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(PatchGeom g, int kind, i
   }
 }
 
-static PatchGeom make_geom(int N, int C, int S, int p) { PatchGeom g; g.N = N; g.C = C; g.S = S; g.p = p; g.G = S / p; g.L = g.G * g.G; g.P = p * p * C; return g; }
+static PatchGeom make_geom(int N, int C, int S, int p) {
+  PatchGeom g; g.N = N; g.C = C; g.S = S; g.p = p; g.G = S / p; g.L = g.G * g.G; g.P = p * p * C;
+  const bool fast = (long long)g.P * (C > p ? C : p) < (1ll << 24);
+  g.mC = fast ? (unsigned)(((1ull << 24) + C - 1) / C) : 0u; g.mp = fast ? (unsigned)(((1ull << 24) + p - 1) / p) : 0u;
+  return g;
+}
 
 extern "C" int csmae_target_minmax(int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
                                    float* scratch /*[B2*L*2]*/, float* out /*[views*2]*/, void* stream) {
