@@ -182,11 +182,13 @@ class Workspace:
         # backward scratch (shared by all layers)
         Mmax_e, Mmax_d = Me, Md
         self.gout = torch.ones(1, **f32)
-        # buffers that the weight-gradient stream reads are ping-ponged so the main chain never waits for it (see Engine._dw)
+        # Buffers that the weight-gradient stream reads rotate so that the main chain never waits for it (see Engine._block_bwd): a
+        # block's ONE grouped launch reads its incoming residual gradient and the one after norm2's backward while the next block is
+        # already writing its own two — five low-precision residual-gradient buffers in rotation, two each of dpre / dqkv.
         self.dres_e = E(Mmax_e, D, **f32)
-        self.dres_e_lp = [E(Mmax_e, D, **lp), E(Mmax_e, D, **lp)]
+        self.dres_e_lp = [E(Mmax_e, D, **lp) for _ in range(5)]
         self.dres_d = E(Mmax_d, Dd, **f32) if eng.res_dtype == torch.float32 else None
-        self.dres_d_lp = [E(Mmax_d, Dd, **lp), E(Mmax_d, Dd, **lp)]
+        self.dres_d_lp = [E(Mmax_d, Dd, **lp) for _ in range(5)]
         big = max(Me * 4 * D, Md * 4 * Dd)
         self.t4 = [E(big, **lp), E(big, **lp)]      # dpre
         self.t3 = [E(max(Me * 3 * D, Md * 3 * Dd), **lp) for _ in range(2)]  # dqkv
@@ -253,9 +255,19 @@ class Engine:
         self.side, self.main, self.aux = None, None, None
         self._fwd_streams = []
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
+        self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
         self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
-        self._dw_pairs = os.environ.get("CSMAE_DW_GROUP", "half") != "none"   # tuning aid: "none" = one launch per product
+        # weight gradients of a block: "half" = two grouped launches (fc2 + fc1 once dpre exists, proj + qkv after attention backward),
+        # "block" = ONE launch when its tiles fit the slots (ViT-B: 108 encoder tiles, no K slice; 48 decoder tiles, 3 slices: 2.5 GB
+        # less slab traffic per step, no fold kernel for the encoder — and measured 0.13 ms SLOWER per step on three boxes: the step is
+        # bound by the main chain, which runs beside a 300-us launch worse than beside two shorter ones), "none" = one per product
+        self._dw_mode = os.environ.get("CSMAE_DW_GROUP", "half")
+        self._dw_rot = self._dw_mode != "half0"   # A/B aid: "half0" = the two-launch mode with its outgoing gradient written over the incoming one (a wait per buffer)
+        if self._dw_mode == "half0":
+            self._dw_mode = "half"
+        if self._dw_mode not in ("block", "half", "none"):
+            raise ValueError(f"CSMAE_DW_GROUP={self._dw_mode!r}: block, half or none")
         sl = flat.slots
         goff = lambda names: torch.tensor([[sl[n + ".weight"][0], sl[n + ".bias"][0]] for n in names], dtype=torch.long, device=self.device)
         self._goff_e = goff([f"encoder.{i}.norm{k}" for i in range(cfg["Ne"]) for k in (1, 2)])
@@ -415,14 +427,23 @@ class Engine:
         grp.launch(self._dw_slots, st=side.cuda_stream)
         done = self._event()
         done.record(side)
+        self._side_seq += 1
         for dy, _, _ in items:
-            self._side_reads[dy.data_ptr()] = done
+            self._side_reads[dy.data_ptr()] = (self._side_seq, done)
 
-    def _guard_write(self, buf):
-        """Main stream is about to overwrite `buf`: wait for the weight-gradient kernel that still reads it (if any)."""
-        ev = self._side_reads.pop(buf.data_ptr(), None)
-        if ev is not None:
-            self.main.wait_event(ev)
+    def _guard_write(self, *bufs):
+        """Main stream is about to overwrite `bufs`: wait for the weight-gradient launches that still read them (if any).  The launches
+        of the side stream finish in order, so ONE wait — for the youngest of them — covers all (every event wait that is enqueued
+        before its event has fired costs the main queue a barrier packet, ~5-8 us of idle chip: DESIGN §5)."""
+        last = None
+        for b in bufs:
+            e = self._side_reads.pop(b.data_ptr(), None)
+            if e is not None and (last is None or e[0] > last[0]):
+                last = e
+        if last is not None:
+            if self._side_waited < last[0]:
+                self.main.wait_event(last[1])
+                self._side_waited = last[0]
 
     def _event(self):
         if self._ev_i == len(self._events):
@@ -433,6 +454,7 @@ class Engine:
     def _join_side(self):
         self.main.wait_stream(self.side)
         self._side_reads.clear()
+        self._side_waited = self._side_seq
 
     # ------------------------------------------------------------------ transformer block
     def _block_fwd(self, S, i, pre, M, Dm, H, B2, T, b0=0, nb=None, st=None):
@@ -462,10 +484,18 @@ class Engine:
         self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=ln, site=k2, a8=e2[0] if e2 else None, emit_site=kh)
         self._mm(h, pre + "mlp.fc2.weight", x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st, lane=ln, site=kh, a8=eh[0] if eh else None)
 
-    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, part):
-        """`lps` = the two ping-pong low-precision copies of the residual gradient; on entry and on exit lps[0] is current.  With a
-        bf16 residual stream they ARE the residual gradient (`dres` is None); with the fp32 stream `dres` is updated in place.
-        `part` = partial-row slices of this block's two LayerNorms (norm1, norm2): their dgamma / dbeta are folded later (_ln_flush)."""
+    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, k, part):
+        """`lps` = the rotating low-precision copies of the residual gradient, lps[k] is current on entry; returns the index that is
+        current on exit.  With a bf16 residual stream they ARE the residual gradient (`dres` is None); with the fp32 stream `dres` is
+        updated in place.  `part` = partial-row slices of this block's two LayerNorms (norm1, norm2): their dgamma / dbeta are folded
+        later (_ln_flush).
+
+        Weight gradients: the block's four products (fc2, fc1, proj, qkv) leave as ONE grouped launch once dqkv exists ("block" mode) —
+        together their tiles fill the launch's workgroups with one K slice (ViT-B encoder: 108 tiles) or three (decoder: 48 tiles)
+        instead of 2-10, so the fp32 slab round trip and the fold kernel all but disappear.  The launch reads four gradient tensors
+        that the main chain would overwrite within two kernels; the block's outgoing residual gradient therefore goes to a third
+        buffer and the next block uses two more (five in rotation), and nothing ever waits for the weight-gradient stream unless it
+        falls two blocks behind."""
         P, st, ws = self.flat.P, self.st, self.ws
         stt = S["st"][i]
         lse = S["lse"][i][: B2 * H * T]
@@ -473,9 +503,18 @@ class Engine:
         dpre = ws.t4[self._tog][: M * 4 * Dm].view(M, 4 * Dm)
         dqkv = ws.t3[self._tog][: M * 3 * Dm].view(M, 3 * Dm)
         t1 = ws.t1[: M * Dm].view(M, Dm)
-        cur, nxt = lps
-        pairs = self._dw_pairs   # the block's four weight gradients go out as two launches: (fc2, fc1) once dpre exists, (proj, qkv) after attention
-        if not pairs:
+        mode = self._dw_mode
+        if mode == "block":   # (wide models: the block's tiles exceed the launch's workgroups — 192 at ViT-L, 300 at ViT-H — and two launches interleave better with the main chain)
+            tiles = sum(-(-a // 256) * -(-b // 256) for a, b in ((Dm, 4 * Dm), (4 * Dm, Dm), (Dm, Dm), (3 * Dm, Dm)))
+            if tiles > self._dw_slots or Dm < 256:
+                mode = "half"
+        n = len(lps)
+        cur, nxt = lps[k], lps[(k + 1) % n]
+        rot = mode == "block" or (mode == "half" and self._dw_rot)
+        out = lps[(k + 2) % n] if rot else cur
+        if rot:   # everything this block writes that an earlier block's launch may still read: one wait (normally for a launch two blocks back)
+            self._guard_write(dpre, nxt, dqkv, out)
+        if mode == "none":
             self._dw(cur, S["h"][i], pre + "mlp.fc2")
         self._guard_write(dpre)
         # (fp8 mode) A operands that their producer already left as fp8 bytes: `cur` (previous LayerNorm backward), dpre (the ×gelu′ epilogue)
@@ -484,9 +523,9 @@ class Engine:
         kd = self._fp8_alloc()
         ed = self._emit(kd, ws.q_b[0], M, 4 * Dm, 1) if self.fp8 else None
         self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
-        if pairs:
+        if mode == "half":
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1")])
-        else:
+        elif mode == "none":
             self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
         self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
         self._guard_write(nxt)
@@ -497,25 +536,29 @@ class Engine:
         else:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, None, None, dres_in=dres, dx_lp=nxt, partial_ws=part[1], st=st)
             en = None
-        if not pairs:
+        if mode == "none":
             self._dw(nxt, S["o"][i], pre + "attn.proj")
         self._mm(nxt, pre + "attn.proj.weight", t1, trans_b=True, st=st, site=kn, a8=en[0] if en else None)
         self._guard_write(dqkv)
         ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
-        if pairs:
+        if mode == "block":
+            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1"),
+                            (nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")])
+        elif mode == "half":
             self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")])
         else:
             self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
         self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st)
-        self._guard_write(cur)
-        kx = self._fp8_alloc() if i > 0 else None     # the next block's fc2-backward reads `cur`
+        self._guard_write(out)
+        kx = self._fp8_alloc() if i > 0 else None     # the next block's fc2-backward reads `out`
         ex = self._emit(kx, ws.q_a[1], M, Dm, 1) if (self.fp8 and dres is None and self._fp8_fuse_lnb) else None
         if dres is None:
-            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), cur, None, None, dres_in=nxt, partial_ws=part[0], emit=ex, st=st)
+            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), out, None, None, dres_in=nxt, partial_ws=part[0], emit=ex, st=st)
         else:
-            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, None, None, dres_in=dres, dx_lp=cur, partial_ws=part[0], st=st)
+            ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), dres, None, None, dres_in=dres, dx_lp=out, partial_ws=part[0], st=st)
         if kx is not None:
             self._fp8_cur = (kx, ex[0] if ex else None)
+        return (k + 2) % n if rot else k
 
     def _ln_flush(self, part, goff, lo, hi, M, Dm):
         """dgamma / dbeta of LayerNorms [lo, hi) of a stack (rows of `part` / `goff`): one deterministic launch."""
@@ -805,10 +848,11 @@ class Engine:
         else:
             ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d, None, None,
                               dx_lp=ws.dres_d_lp[0], partial_ws=pd[Nd2], st=st)
+        kd_ = 0
         for i in reversed(range(c["Nd"])):
-            self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp, (pd[2 * i], pd[2 * i + 1]))
+            kd_ = self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp, kd_, (pd[2 * i], pd[2 * i + 1]))
         self._ln_flush(pd, self._goff_d, 0, Nd2 + 1, ws.Md, Dd)
-        ops.unshuffle_bwd(ws.dres_d_lp[0] if lp_stream else ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
+        ops.unshuffle_bwd(ws.dres_d_lp[kd_] if lp_stream else ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
         lat_op = ws.enc["x"][c["Ne"]] if (lp_stream or self.T != BF16) else ws.lat_lp
         self._dw(ws.dz_lp, lat_op, "decoder_embed")
         ops.gemm(ws.dz_lp, self.W("decoder_embed.weight"), ws.dres_e, trans_b=True, st=st)
@@ -828,14 +872,15 @@ class Engine:
         ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp[0], B2, Te, st=st)
         self._fp8_cur = None
         pe, flushed = ws.ln_part_e, c["Ne"]
+        ke_ = 0
         for i in reversed(range(c["Ne"])):
-            self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, None if lp_stream else ws.dres_e, ws.dres_e_lp, (pe[2 * i], pe[2 * i + 1]))
+            ke_ = self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, None if lp_stream else ws.dres_e, ws.dres_e_lp, ke_, (pe[2 * i], pe[2 * i + 1]))
             if dp is not None and dp.wants(("enc", i)):
                 self._ln_flush(pe, self._goff_e, 2 * i, 2 * flushed, ws.Me, D)   # the bucket's LayerNorm gradients must be final before its exchange
                 flushed = i
                 dp.grads_ready(self.flat, ("enc", i), also=self.side if not (ops._timer is not None or os.environ.get("CSMAE_DW_MAIN")) else None)
         self._ln_flush(pe, self._goff_e, 0, 2 * flushed, ws.Me, D)
-        ops.embed_assemble_bwd(ws.dres_e_lp[0] if lp_stream else ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
+        ops.embed_assemble_bwd(ws.dres_e_lp[ke_] if lp_stream else ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
         self._join_side()
         ops.DwGroup([(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), G("patch_embed.proj.bias"))], ws.dw_ws).launch(256, st=st)
         if dp is not None:

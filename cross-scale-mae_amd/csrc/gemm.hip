@@ -232,30 +232,34 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   }
   const bf16_t* LS = EPI == EPI_RESID ? reinterpret_cast<const bf16_t*>(p.resid) : X;   // what the phase loads: bf16 residual stream / gelu'
   const long long lds_ = EPI == EPI_RESID ? p.ldr : p.ldaux;
-  uint4 ld[NEEDS_LOAD ? NPASS : 1];
+  // Loads of part p + 1 are issued BEFORE the stores of part p and nothing waits for a store: vmcnt retires loads and stores in issue
+  // order, so a `vmcnt(0)` in front of every part (the first version) made each part wait for the previous part's stores to be
+  // acknowledged by memory — three store round trips, over half of the epilogue's 7 k clocks per tile.
+  uint4 ld[2][NPASS];   // (dead code unless NEEDS_LOAD)
+  auto load_part = [&](int part, uint4 (&dst)[NPASS]) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
+      const bf16_t* src = LS + (long long)gm * lds_ + gn;
+      dst[ps] = make_uint4(0, 0, 0, 0);
+      if (EPI == EPI_DGELU && p.aux_q8) {   // one byte per element: 8 (4) bytes per lane
+        const unsigned char* s8 = reinterpret_cast<const unsigned char*>(p.aux) + (long long)gm * p.ldaux + gn;
+        if (ok1) { const uint2 h = *reinterpret_cast<const uint2*>(s8); dst[ps].x = h.x; dst[ps].y = h.y; }
+        else if (ok0) dst[ps].x = *reinterpret_cast<const unsigned*>(s8);
+      }
+      else if (ok1) dst[ps] = *reinterpret_cast<const uint4*>(src);
+      else if (ok0) { const uint2 h = *reinterpret_cast<const uint2*>(src); dst[ps].x = h.x; dst[ps].y = h.y; }
+    }
+  };
+  if (NEEDS_LOAD) load_part(0, ld[0]);
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
-    if (NEEDS_LOAD) {
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int gm = min(mbase + part * EROWS + ps * RPP + rsub, p.M - 1);
-        const bf16_t* src = LS + (long long)gm * lds_ + gn;
-        ld[ps] = make_uint4(0, 0, 0, 0);
-        if (EPI == EPI_DGELU && p.aux_q8) {   // one byte per element: 8 (4) bytes per lane
-          const unsigned char* s8 = reinterpret_cast<const unsigned char*>(p.aux) + (long long)gm * p.ldaux + gn;
-          if (ok1) { const uint2 h = *reinterpret_cast<const uint2*>(s8); ld[ps].x = h.x; ld[ps].y = h.y; }
-          else if (ok0) ld[ps].x = *reinterpret_cast<const unsigned*>(s8);
-        }
-        else if (ok1) ld[ps] = *reinterpret_cast<const uint4*>(src);
-        else if (ok0) { const uint2 h = *reinterpret_cast<const uint2*>(src); ld[ps].x = h.x; ld[ps].y = h.y; }
-      }
-    }
 #pragma unroll
     for (int ii = 0; ii < EROWS / 16; ++ii)
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = acc[part * (EROWS / 16) + ii][j];
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every load of this phase has landed, the stores below go out back to back
+    if (NEEDS_LOAD && part + 1 < NPART) load_part(part + 1, ld[(part + 1) & 1]);
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int gm = mbase + part * EROWS + ps * RPP + rsub;
@@ -264,7 +268,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
       f4_t o0 = v0, o1 = v1;
       if (EPI == EPI_GELU) { const f4_t x0 = v0, x1 = v1; gelu_both4<bf16_t>(x0, o0, v0); gelu_both4<bf16_t>(x1, o1, v1); }
       if (EPI == EPI_DGELU || EPI == EPI_RESID) {
-        const uint4 a = ld[ps];
+        const uint4 a = ld[part & 1][ps];
         f4_t a0 = f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
         f4_t a1 = f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
         if (EPI == EPI_DGELU && p.aux_q8) { a0 = gp_q8_unpack4(a.x); a1 = gp_q8_unpack4(a.y); }
