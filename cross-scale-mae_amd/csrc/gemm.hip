@@ -315,6 +315,45 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   }
 }
 
+// bf16 output with nothing but the bias to add (qkv forward, the dX products of fc1 / qkv / proj): the tile crosses the strip as bf16,
+// not as fp32.  A 256 x 256 tile's epilogue (7 k clocks at K = 512 .. 768, a quarter of the tile) spent 3.3 k of them pushing 256 KiB
+// of fp32 accumulators through ds_write_b128 (13 clocks per KiB); rounding first halves the bytes written and read and leaves the
+// row-segment pass with nothing to compute.  The arithmetic is unchanged (acc + bias in fp32, one rounding): bit-identical outputs.
+template <int FM, int FN, int WM>
+__device__ __forceinline__ void epilogue_rows_bf16_plain(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], char* ew, int mbase, int nbase, int lane, int t, int g) {
+  constexpr int WN = FN * 16, ROWB = WN * 2 + 8, EROWS = (WM % 64 == 0) ? 64 : 32, NPART = WM / EROWS, LPR = WN / 8, RPP = 64 / LPR, NPASS = EROWS / RPP;
+  static_assert(WM % EROWS == 0 && EROWS * ROWB <= 32 * (WN + 4) * 4, "the bf16 strip reuses the fp32 strip's bytes");
+  f4_t bj[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = nbase + j * 16 + 4 * g;
+    bj[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f4_t*>(p.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const int col = (lane % LPR) * 8, rsub = lane / LPR;
+  const int gn = nbase + col;
+  const bool ok0 = gn < p.N, ok1 = gn + 4 < p.N;
+  bf16_t* C = reinterpret_cast<bf16_t*>(Cptr);
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) {
+#pragma unroll
+    for (int ii = 0; ii < EROWS / 16; ++ii)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const f4_t v = acc[part * (EROWS / 16) + ii][j] + bj[j];
+        *reinterpret_cast<uint2*>(ew + (ii * 16 + t) * ROWB + (j * 16 + 4 * g) * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int r = ps * RPP + rsub, gm = mbase + part * EROWS + r;
+      const uint4 v = *reinterpret_cast<const uint4*>(ew + r * ROWB + col * 2);
+      if (gm < p.M) {
+        if (ok1) *reinterpret_cast<uint4*>(C + (long long)gm * p.ldc + gn) = v;
+        else if (ok0) *reinterpret_cast<uint2*>(C + (long long)gm * p.ldc + gn) = make_uint2(v.x, v.y);
+      }
+    }
+  }
+}
+
 template <bool TA, bool TB, int BM, int BN, int WM, int WN, int GEMM_STAGES, bool DB, int MINW = 1>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, FM = WM / 16, FN = WN / 16;
@@ -833,7 +872,9 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
                                                                                    : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));  // 16-byte row segments
   if (p.c_dtype == CSMAE_BF16) {
-    if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
+    if (wide && p.epi == EPI_NONE && p.q_out == nullptr)
+      epilogue_rows_bf16_plain<FM, FN, WM>(p, Cptr, acc, reinterpret_cast<char*>(ew), m0 + wm, n0 + wn, lane, t, g);
+    else if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
     else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
     else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
     else EPI_CALL(bf16_t, EPI_NONE);

@@ -407,6 +407,29 @@ def test_gemm_residual_epilogue_bf16_stream(ops):
             ops.gemm(dev(a), dev(w), out, bias=dev(bias), epilogue=EPI_RESID, resid=dev(resid.float()))
 
 
+def test_gemm_plain_epilogue_bf16_is_the_rounded_fp32_result(ops):
+    """The bias-only bf16 epilogue sends the tile through LDS already rounded (csrc/gemm.hip epilogue_rows_bf16_plain); the fp32-output
+    epilogue of the same kernel keeps acc + bias in fp32.  Same accumulators, one rounding: the bf16 output must equal the fp32
+    output rounded to nearest even, bit for bit — on 256- and 192-row tiles, ragged M, an N that ends inside a lane's 8 columns
+    (row pitch a multiple of 8, so the 16-byte-row path is taken) and both K-contiguous-A layouts."""
+    for M, N, K, pitch in ((512, 512, 512, 512), (400, 768, 256, 768), (1000, 516, 320, 520), (777, 260, 1000, 264), (2048, 2304, 768, 2304)):
+        for tb in (False, True):
+            a = rnd(M, K, seed=60).to(torch.bfloat16)
+            w = (rnd(K, pitch, seed=61) * 0.05).to(torch.bfloat16)[:, :N] if tb else (rnd(N, K, seed=61) * 0.05).to(torch.bfloat16)
+            bias = rnd(N, seed=62)
+            o16 = torch.zeros(M, pitch, device="cuda", dtype=torch.bfloat16)[:, :N]
+            o32 = torch.zeros(M, pitch, device="cuda", dtype=torch.float32)[:, :N]
+            wd = dev(torch.zeros(K, pitch, dtype=torch.bfloat16))[:, :N] if tb else None
+            if tb:
+                wd.copy_(w)
+            ops.gemm(dev(a), wd if tb else dev(w), o16, trans_b=tb, bias=dev(bias))
+            ops.gemm(dev(a), wd if tb else dev(w), o32, trans_b=tb, bias=dev(bias))
+            assert torch.equal(o16.contiguous().view(torch.int16), o32.to(torch.bfloat16).contiguous().view(torch.int16)), \
+                f"plain bf16 epilogue {M}x{N}x{K} trans_b={tb}"
+            ref = a.float() @ (w.float() if tb else w.float().t()) + bias
+            assert_close(o16, ref, 1e-2, 2e-2, f"gemm plain bf16 {M}x{N}x{K} trans_b={tb}")
+
+
 def test_gemm_gelu_epilogues_with_8bit_derivative(ops):
     """fc1 epilogue: C = gelu(x), aux = gelu'(x) stored as one byte (q = round((g + 0.13) * 255 / 1.26)); fc2-backward epilogue: C = acc * aux.
     The code's resolution is 1.26 / 255 = 4.9e-3, i.e. |error| <= 2.5e-3; on the pipelined-kernel shapes and on a small one."""
