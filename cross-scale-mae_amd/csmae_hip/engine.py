@@ -258,6 +258,10 @@ class Engine:
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
         self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
+        # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
+        # 128 workgroups = 4 / 8 whole K slices of its 32- and 16-tile launches (160 -> 128: -0.15 .. -0.3 ms per step; 64: +1.4 ms)
+        se = os.environ.get("CSMAE_DW_SLOTS_ED", "" if "CSMAE_DW_SLOTS" in os.environ else "160,128")
+        self._dw_slots_ed = tuple(int(v) for v in se.split(",")) if se else None
         # weight gradients of a block: "half" = two grouped launches (fc2 + fc1 once dpre exists, proj + qkv after attention backward),
         # "block" = ONE launch when its tiles fit the slots (ViT-B: 108 encoder tiles, no K slice; 48 decoder tiles, 3 slices: 2.5 GB
         # less slab traffic per step, no fold kernel for the encoder — and measured 0.13 ms SLOWER per step on three boxes: the step is
@@ -266,8 +270,8 @@ class Engine:
         self._dw_rot = self._dw_mode != "half0"   # A/B aid: "half0" = the two-launch mode with its outgoing gradient written over the incoming one (a wait per buffer)
         if self._dw_mode == "half0":
             self._dw_mode = "half"
-        if self._dw_mode not in ("block", "half", "none"):
-            raise ValueError(f"CSMAE_DW_GROUP={self._dw_mode!r}: block, half or none")
+        if self._dw_mode not in ("block", "block_enc", "block_dec", "half", "none"):
+            raise ValueError(f"CSMAE_DW_GROUP={self._dw_mode!r}: block, block_enc, block_dec, half or none")
         sl = flat.slots
         goff = lambda names: torch.tensor([[sl[n + ".weight"][0], sl[n + ".bias"][0]] for n in names], dtype=torch.long, device=self.device)
         self._goff_e = goff([f"encoder.{i}.norm{k}" for i in range(cfg["Ne"]) for k in (1, 2)])
@@ -402,7 +406,7 @@ class Engine:
         """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored)."""
         self._dw_group([(dy, x, name)])
 
-    def _dw_group(self, items):
+    def _dw_group(self, items, slots=None):
         """Weight gradients of several Linear layers over the same tokens, [(dy, x, name)], in one launch (csmae_gemm_dw_group: the
         products share the chip, K slices are folded inside the kernel, the result goes straight into the gradient buffer).
 
@@ -424,7 +428,7 @@ class Engine:
         ev = self._event()
         ev.record(self.main)
         side.wait_event(ev)
-        grp.launch(self._dw_slots, st=side.cuda_stream)
+        grp.launch(slots or self._dw_slots, st=side.cuda_stream)
         done = self._event()
         done.record(side)
         self._side_seq += 1
@@ -504,6 +508,8 @@ class Engine:
         dqkv = ws.t3[self._tog][: M * 3 * Dm].view(M, 3 * Dm)
         t1 = ws.t1[: M * Dm].view(M, Dm)
         mode = self._dw_mode
+        if mode in ("block_enc", "block_dec"):   # A/B aid: the one-launch form for one of the two stacks only
+            mode = "block" if (mode == "block_enc") == (S is ws.enc) else "half"
         if mode == "block":   # (wide models: the block's tiles exceed the launch's workgroups — 192 at ViT-L, 300 at ViT-H — and two launches interleave better with the main chain)
             tiles = sum(-(-a // 256) * -(-b // 256) for a, b in ((Dm, 4 * Dm), (4 * Dm, Dm), (Dm, Dm), (3 * Dm, Dm)))
             if tiles > self._dw_slots or Dm < 256:
@@ -523,8 +529,9 @@ class Engine:
         kd = self._fp8_alloc()
         ed = self._emit(kd, ws.q_b[0], M, 4 * Dm, 1) if self.fp8 else None
         self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
+        slots = self._dw_slots_ed[0 if S is ws.enc else 1] if self._dw_slots_ed else None
         if mode == "half":
-            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1")])
+            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1")], slots)
         elif mode == "none":
             self._dw(dpre, S["y2"][i], pre + "mlp.fc1")
         self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
@@ -543,9 +550,9 @@ class Engine:
         ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
         if mode == "block":
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, S["y2"][i], pre + "mlp.fc1"),
-                            (nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")])
+                            (nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")], slots)
         elif mode == "half":
-            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")])
+            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, S["y1"][i], pre + "attn.qkv")], slots)
         else:
             self._dw(dqkv, S["y1"][i], pre + "attn.qkv")
         self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st)
