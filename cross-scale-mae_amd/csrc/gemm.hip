@@ -235,6 +235,10 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   // Loads of part p + 1 are issued BEFORE the stores of part p and nothing waits for a store: vmcnt retires loads and stores in issue
   // order, so a `vmcnt(0)` in front of every part (the first version) made each part wait for the previous part's stores to be
   // acknowledged by memory — three store round trips, over half of the epilogue's 7 k clocks per tile.
+  // (8-bit gelu' stores in 16-byte pieces, see the store loop: rows of aux 16-byte aligned, passes in pairs, all 16 columns of a lane pair inside N)
+  const bool gp16 = EPI == EPI_GELU && p.aux_q8 && (NPASS % 2 == 0) && p.ldaux % 16 == 0 && ((uintptr_t)p.aux & 15) == 0;
+  const bool pair_ok = nbase + ((lane % LPR) & ~1) * 8 + 16 <= p.N;
+  uint2 gp_prev = make_uint2(0u, 0u);
   uint4 ld[2][NPASS];   // (dead code unless NEEDS_LOAD)
   auto load_part = [&](int part, uint4 (&dst)[NPASS]) {
 #pragma unroll
@@ -293,12 +297,31 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
         if (ok1) *reinterpret_cast<uint2*>(qd) = make_uint2((unsigned)w0, (unsigned)w1);
         else *reinterpret_cast<unsigned*>(qd) = (unsigned)w0;
       }
-      if (gm < p.M) {
-        if (EPI == EPI_GELU && p.aux_q8) {
-          unsigned char* d8 = reinterpret_cast<unsigned char*>(p.aux) + (long long)gm * p.ldaux + gn;
-          if (ok1) *reinterpret_cast<uint2*>(d8) = make_uint2(gp_q8_pack4(v0), gp_q8_pack4(v1));
-          else if (ok0) *reinterpret_cast<unsigned*>(d8) = gp_q8_pack4(v0);
+      if (EPI == EPI_GELU && p.aux_q8) {
+        // 8-bit gelu': a lane's 8 columns are 8 bytes, and this epilogue is bound by the NUMBER of store instructions its CU issues.
+        // Neighbouring lanes (columns 16k.. and 16k+8.. of one row) trade the codes of two consecutive passes, so that the even
+        // lane stores 16 bytes of the first pass's row and the odd lane 16 bytes of the second's: one gelu' store per two passes.
+        const uint2 mine = make_uint2(gp_q8_pack4(v0), gp_q8_pack4(v1));
+        unsigned char* a8 = reinterpret_cast<unsigned char*>(p.aux);
+        auto st8 = [&](int row, uint2 v) {
+          if (row >= p.M) return;
+          unsigned char* d8 = a8 + (long long)row * p.ldaux + gn;
+          if (ok1) *reinterpret_cast<uint2*>(d8) = v;
+          else if (ok0) *reinterpret_cast<unsigned*>(d8) = v.x;
+        };
+        if (!gp16) st8(gm, mine);
+        else if ((ps & 1) == 0) gp_prev = mine;
+        else {
+          const bool odd = lane & 1;
+          const uint2 send = odd ? gp_prev : mine;
+          uint2 recv;
+          recv.x = (unsigned)__shfl_xor((int)send.x, 1); recv.y = (unsigned)__shfl_xor((int)send.y, 1);
+          if (!pair_ok) { st8(gm - RPP, gp_prev); st8(gm, mine); }
+          else if (!odd) { if (gm - RPP < p.M) *reinterpret_cast<uint4*>(a8 + (long long)(gm - RPP) * p.ldaux + gn) = make_uint4(gp_prev.x, gp_prev.y, recv.x, recv.y); }
+          else if (gm < p.M) *reinterpret_cast<uint4*>(a8 + (long long)gm * p.ldaux + gn - 8) = make_uint4(recv.x, recv.y, mine.x, mine.y);
         }
+      }
+      if (gm < p.M) {
         if (ok1) {
           if (EPI == EPI_GELU && !p.aux_q8) *reinterpret_cast<uint4*>(X + (long long)gm * p.ldaux + gn) = make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
           *reinterpret_cast<uint4*>(C + (long long)gm * p.ldc + gn) = make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));

@@ -452,6 +452,22 @@ def test_gemm_gelu_epilogues_with_8bit_derivative(ops):
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ops.gemm(dev(dy), dev(w2), out, trans_b=True, epilogue=EPI_DGELU, aux=gq)
         assert_close(out, (dy.float() @ w2.float()) * dec, 1e-2, 2e-2, f"dgelu q8 {M}x{N}")
+    # The codes leave in 16-byte pieces (two lanes trade the codes of two passes) when the rows of aux are 16-byte aligned, in 8-byte
+    # pieces otherwise: both forms must write the same bytes — full tiles, ragged M, and an N that ends inside a lane pair's 16 columns.
+    for M, N, K, pitch in ((512, 1024, 256, 1024), (777, 520, 192, 528), (300, 264, 128, 272)):
+        a = dev(rnd(M, K, seed=95).to(torch.bfloat16))
+        w = dev((rnd(N, K, seed=96) * 0.12).to(torch.bfloat16))
+        bias = dev(rnd(N, seed=97) * 0.5)
+        h1, h2 = (torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+        g1 = torch.zeros(M, pitch, device="cuda", dtype=torch.uint8)[:, :N]
+        raw = torch.zeros(M * pitch + 16, device="cuda", dtype=torch.uint8)
+        off = 8 if raw.data_ptr() % 16 == 0 else 0            # rows 8 (mod 16) bytes off: the 8-byte form
+        g2 = raw[off:off + M * pitch].view(M, pitch)[:, :N]
+        assert g1.data_ptr() % 16 == 0 and g2.data_ptr() % 16 == 8
+        ops.gemm(a, w, h1, bias=bias, epilogue=EPI_GELU, aux=g1)
+        ops.gemm(a, w, h2, bias=bias, epilogue=EPI_GELU, aux=g2)
+        assert torch.equal(g1, g2) and torch.equal(h1, h2), f"8-bit gelu' store forms differ {M}x{N}"
+        assert int(g1.max()) > 200 and int(g1.min()) < 30      # (codes actually written)
 
 
 def test_stack_boundaries_bf16_stream(ops):
