@@ -492,6 +492,183 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   }
 }
 
+// ---- the same pass with TWO key pairs per wave and a single sweep (NP <= 8 key pairs: every shape of the step).  The two-sweep form
+// above walks the query pairs twice — 2 NP steps, each with its Q / dO fragment reads, one read-modify-write of the step's dQ rows in
+// LDS and a workgroup barrier.  Here wave w owns key pairs w and w + 4 at once: one walk (NP steps and barriers), the Q / dO fragments
+// of a step (row and transposed forms) are read once for both key pairs, and the step's dQ contribution of 64 keys is summed in
+// registers before its single read-modify-write.
+template <int HD, int NKF>
+__global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale) {
+  using L = AttnBwd1p<HD, NKF>;
+  constexpr int TP = L::TP, NP = L::NP, KS = HD / 32, DF = HD / 16, IMG = L::IMG, QS = L::QS;
+  static_assert(NP <= 8, "two key pairs per wave cover at most eight");
+  // NPW key pairs per wave; a pair beyond the sequence is skipped (computing it unconditionally — all-zero K / V, so that both chains
+  // of a step share a basic block — measured slower: 193 vs 183 us, the idle wave's SIMD belongs to the other workgroup's waves)
+  constexpr int NPW = NP > 4 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char smem[L::LDS];
+  char* Qs = smem; char* Gs = smem + IMG;
+  float* dqa = reinterpret_cast<float*>(smem + 2 * IMG);
+  char* xall = smem + 2 * IMG + TP * QS * 4;
+  float* lse2 = reinterpret_cast<float*>(xall + 4 * L::XB);
+  float* dl = lse2 + TP;
+  const int wid = pair_remap<HD>(blockIdx.x, gridDim.x);
+  const int b = wid / H, h = wid - b * H;
+  const long long row0 = (long long)b * T;
+  const int ld = 3 * D;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  HeadStager<HD, TP, 256, 2> sg;
+  sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
+  const int nkp = (T + 31) >> 5;
+  uint4 kraw[NPW][2][KS], vraw[NPW][2][KS];   // [pair][tile][k step]
+#pragma unroll
+  for (int pi = 0; pi < NPW; ++pi)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kp = w + 4 * pi, key = 32 * kp + 16 * jj + t, col = ks * 32 + 8 * g;
+        kraw[pi][jj][ks] = make_uint4(0, 0, 0, 0); vraw[pi][jj][ks] = make_uint4(0, 0, 0, 0);
+        if (kp < nkp && key < T && col < hd) {
+          kraw[pi][jj][ks] = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + D + h * hd + col);
+          vraw[pi][jj][ks] = *reinterpret_cast<const uint4*>(qkv + (row0 + key) * ld + 2 * D + h * hd + col);
+        }
+      }
+  for (int e = threadIdx.x; e < TP * QS / 4; e += blockDim.x) reinterpret_cast<f4_t*>(dqa)[e] = f4_t{0.f, 0.f, 0.f, 0.f};
+  for (int r = threadIdx.x; r < TP; r += blockDim.x) {
+    float acc = 0.f, l2 = INFINITY;
+    if (r < T) {
+      l2 = lse[((long long)b * H + h) * T + r] * LOG2E;
+      const bf16_t* o = out + (row0 + r) * D + h * hd;
+      const bf16_t* gg = dout + (row0 + r) * D + h * hd;
+      uint4 ov[HD / 8], gv[HD / 8];
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        ov[c] = c * 8 < hd ? *reinterpret_cast<const uint4*>(o + c * 8) : make_uint4(0, 0, 0, 0);
+        gv[c] = c * 8 < hd ? *reinterpret_cast<const uint4*>(gg + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        const unsigned ow[4] = {ov[c].x, ov[c].y, ov[c].z, ov[c].w}, gw[4] = {gv[c].x, gv[c].y, gv[c].z, gv[c].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          acc += __uint_as_float(ow[k] << 16) * __uint_as_float(gw[k] << 16) + __uint_as_float(ow[k] & 0xffff0000u) * __uint_as_float(gw[k] & 0xffff0000u);
+      }
+    }
+    lse2[r] = l2; dl[r] = acc;
+  }
+  sg.store(0, Qs); sg.store(1, Gs);
+  const float c2 = scale * LOG2E;
+  char* xw = xall + w * L::XB;
+  const int nq = (T + 31) >> 5;
+  const bool act0 = w < nkp, act1 = w + 4 < nkp;   // (wave-uniform)
+  s8_t fk[NPW][2][KS], fv[NPW][2][KS], kT[NPW][DF];
+  f4_t dk[NPW][2][DF], dv[NPW][2][DF];
+#pragma unroll
+  for (int pi = 0; pi < NPW; ++pi) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int col = ks * 32 + 8 * g;
+        fk[pi][jj][ks] = __builtin_bit_cast(s8_t, kraw[pi][jj][ks]); fv[pi][jj][ks] = __builtin_bit_cast(s8_t, vraw[pi][jj][ks]);
+        *reinterpret_cast<uint4*>(xw + (16 * jj + t) * (HD * 2) + col * 2) = kraw[pi][jj][ks];   // K rows -> patch -> K^T (the patch is wave-private: LDS operations of a wave stay in order)
+      }
+#pragma unroll
+    for (int df = 0; df < DF; ++df) kT[pi][df] = patch_cols_tr<HD>(xw, df * 16, t, g);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int df = 0; df < DF; ++df) { dk[pi][jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; dv[pi][jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; }
+  }
+  __syncthreads();                          // staging, statistics and the cleared accumulator are visible
+  for (int s = 0; s < nq; ++s) {
+    int ip = w + s; if (ip >= nq) ip -= nq;
+    const int q0 = 32 * ip;
+    if (act0) {
+      s8_t fq[2][KS], fg[2][KS], qT[DF], gT[DF];
+      f4_t l4[2], d4[2], dq[2][DF];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { fq[ii][ks] = frag_rows<HD>(Qs, q0 + 16 * ii, ks, t, g); fg[ii][ks] = frag_rows<HD>(Gs, q0 + 16 * ii, ks, t, g); }
+        l4[ii] = *reinterpret_cast<const f4_t*>(lse2 + q0 + 16 * ii + 4 * g);
+        d4[ii] = *reinterpret_cast<const f4_t*>(dl + q0 + 16 * ii + 4 * g);
+#pragma unroll
+        for (int df = 0; df < DF; ++df) dq[ii][df] = f4_t{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int df = 0; df < DF; ++df) { qT[df] = frag_cols_tr<HD>(Qs, q0, df * 16, t, g); gT[df] = frag_cols_tr<HD>(Gs, q0, df * 16, t, g); }
+#pragma unroll
+      for (int pi = 0; pi < NPW; ++pi) {
+        if (pi == 1 && !act1) continue;
+        uint2 pp[2][2], dsp[2][2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            f4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { a = MFMA16(fq[ii][ks], fk[pi][jj][ks], a); dp = MFMA16(fg[ii][ks], fv[pi][jj][ks], dp); }
+            f4_t p, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              p[r] = __builtin_amdgcn_exp2f(a[r] * c2 - l4[ii][r]);  // padded queries: lse2 = +inf -> p = 0
+              ds[r] = p[r] * (dp[r] - d4[ii][r]) * scale;
+            }
+            pp[ii][jj] = make_uint2(pack2bf(p[0], p[1]), pack2bf(p[2], p[3]));
+            const uint2 u = make_uint2(pack2bf(ds[0], ds[1]), pack2bf(ds[2], ds[3]));
+            dsp[ii][jj] = u;
+            *reinterpret_cast<uint2*>(xw + (ii * 2 + jj) * 512 + t * 32 + g * 8) = u;   // dS tile -> patch [ii][jj][key t][query 4g..4g+3]
+          }
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            dk[pi][jj][df] = MFMA16(qT[df], __builtin_bit_cast(s8_t, make_uint4(dsp[0][jj].x, dsp[0][jj].y, dsp[1][jj].x, dsp[1][jj].y)), dk[pi][jj][df]);
+            dv[pi][jj][df] = MFMA16(gT[df], __builtin_bit_cast(s8_t, make_uint4(pp[0][jj].x, pp[0][jj].y, pp[1][jj].x, pp[1][jj].y)), dv[pi][jj][df]);
+          }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const char* xp = xw + ii * 1024 + (4 * g + (t >> 2)) * 32 + (t & 3) * 8;
+          s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, xp));
+          s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s4_t, xp + 512));
+          const s8_t sT = join_s4(lo, hi);
+#pragma unroll
+          for (int df = 0; df < DF; ++df) dq[ii][df] = MFMA16(kT[pi][df], sT, dq[ii][df]);
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        f4_t* dst = reinterpret_cast<f4_t*>(dqa + (q0 + 16 * ii + t) * QS + 4 * g);
+#pragma unroll
+        for (int df = 0; df < DF; ++df) dst[df * 4] += dq[ii][df];
+      }
+    }
+    __syncthreads();                        // the rows this wave updated belong to another wave in the next step
+  }
+#pragma unroll
+  for (int pi = 0; pi < NPW; ++pi) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int key = 32 * (w + 4 * pi) + 16 * jj + t;
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const int d = df * 16 + 4 * g;
+        if (key < T && d < hd) {
+          st4<bf16_t>(dqkv + (row0 + key) * ld + D + h * hd + d, dk[pi][jj][df]);
+          st4<bf16_t>(dqkv + (row0 + key) * ld + 2 * D + h * hd + d, dv[pi][jj][df]);
+        }
+      }
+    }
+  }
+  for (int e = threadIdx.x; e < T * (HD / 4); e += blockDim.x) {
+    const int q = e / (HD / 4), d = (e - q * (HD / 4)) * 4;
+    if (d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d));
+  }
+}
+
 // ------------------------------------------------------------------------------------------ fp32 (parity mode)
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qkv, float* __restrict__ out,
@@ -605,7 +782,12 @@ static void launch_fwd_bf16(int BH, const void* qkv, void* out, float* lse, int 
 template <int HD, int NKF>
 static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int T, int H, int D, int hd, float scale, hipStream_t st) {
   static const bool two_pass = getenv("CSMAE_ATTN_BWD_2PASS") != nullptr;  // tuning aid: the older two-pass kernel
-  if (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 && NKF >= 6 && !two_pass)  // (<= 64 tokens: fewer key pairs than waves, the two-pass split is faster)
+  static const bool two_sweeps = getenv("CSMAE_ATTN_BWD_2SWEEP") != nullptr;  // tuning aid: one key pair per wave and sweep (the first single-pass version)
+  constexpr bool KP2_OK = HD <= 32 && NKF >= 6 && NKF <= 16 && AttnBwd1p<HD, NKF>::LDS <= 160 * 1024;
+  if (KP2_OK && !two_pass && !two_sweeps)
+    hipLaunchKernelGGL((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
+  else if (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 && NKF >= 6 && !two_pass)  // (<= 64 tokens: fewer key pairs than waves, the two-pass split is faster)
     hipLaunchKernelGGL((attn_bwd1p_bf16<HD, (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
   else
