@@ -33,7 +33,8 @@ class GradSync:
         self.stream = torch.cuda.Stream() if self.cuda else None
         self._staging = torch.empty(flat_grad.numel(), dtype=comm_dtype, device=flat_grad.device) if comm_dtype not in (None, flat_grad.dtype) else None
         self._pending = False
-        self.issued = []   # (lo, hi) of the ranges exchanged since the last finish() (tests read it)
+        self.issued = []   # (lo, hi) of the ranges exchanged by the current / last backward pass: cleared by the first reduce_range() after a finish() (tests read it)
+        self._fresh = True
         # gloo has no AVG; RCCL does
         self._avg = self.cuda and is_dist() and dist.get_backend(group) == "nccl"
 
@@ -43,6 +44,9 @@ class GradSync:
         are not made to wait for each other — only the exchange waits."""
         if (self.world == 1 and not self.force) or hi <= lo:
             return
+        if self._fresh:   # (one (lo, hi) per bucket and step: without this the list grows for the length of the training run)
+            self.issued.clear()
+            self._fresh = False
         self.issued.append((lo, hi))
         seg = self.g[lo:hi]
         if self.cuda:
@@ -56,11 +60,19 @@ class GradSync:
             self._reduce(seg, lo, hi)
 
     def _reduce(self, seg, lo, hi):
-        if self._staging is not None:  # bf16 payload: halves xGMI bytes (SURVEY.md §8e budget)
+        if self._staging is not None:  # bf16 payload (opt-in): halves xGMI bytes (SURVEY.md §8e budget)
             st = self._staging[lo:hi]
-            st.copy_(seg)
+            hip = self.cuda and seg.dtype == torch.float32 and st.dtype == torch.bfloat16   # the two casts are HIP kernels on the exchange stream
+            if hip:
+                from . import ops
+                ops.cast_bf16(seg, st)
+            else:   # (CPU / gloo tests of the control flow)
+                st.copy_(seg)
             dist.all_reduce(st, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group)
-            seg.copy_(st)
+            if hip:
+                ops.cast_f32(st, seg)
+            else:
+                seg.copy_(st)
             if not self._avg:
                 seg.div_(self.world)
         elif self._avg:
@@ -74,6 +86,7 @@ class GradSync:
         if self._pending:
             torch.cuda.current_stream().wait_stream(self.stream)
             self._pending = False
+        self._fresh = True
 
     def broadcast(self, tensors: List[torch.Tensor], src: int = 0):
         if self.world == 1 and not self.force:
@@ -144,10 +157,10 @@ class DataParallel(torch.nn.Module):
     """Wrapper with DDP's surface (`.module`, forward passthrough, `no_sync()`): hooks the engine's backward so gradient
     ranges are all-reduced as soon as they are final."""
 
-    def __init__(self, module, device_ids=None, find_unused_parameters=False, comm_dtype="auto", force_collectives: bool = False, **_):
-        """comm_dtype: gradient payload on the wire.  "auto" (default): bf16 when the model computes in bf16 / fp8 (throughput mode:
-        the weight gradients come out of bf16 operands anyway, and half the xGMI bytes is what SURVEY §8e's budget needs), fp32 in
-        parity mode; or an explicit torch dtype / None (= fp32)."""
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, comm_dtype=None, force_collectives: bool = False, **_):
+        """comm_dtype: gradient payload on the wire.  None (default) = fp32, what the reference's DDP exchanges (main_pretrain.py:417-421)
+        and the only payload until an 8-GPU run has validated another one; torch.bfloat16 halves the xGMI bytes (opt-in); "auto" = bf16
+        when the engine that owns the flat buffers computes in bf16 / fp8 (it has a bf16 weight mirror), fp32 in parity mode."""
         super().__init__()
         self.module = module
         self.comm_dtype = comm_dtype
@@ -159,14 +172,12 @@ class DataParallel(torch.nn.Module):
     def _ensure(self, flat):
         if self._sync is None or self._sync.g is not flat.g:
             cd = self.comm_dtype
-            if isinstance(cd, str):   # "auto"
-                mode = self.module.compute_dtype
-                if mode is None:
-                    mode = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
-                cd = None if mode == torch.float32 else torch.bfloat16
+            if isinstance(cd, str):   # "auto": from the engine's own numerics mode (a bf16 weight mirror exists), never from ambient autocast state
+                cd = torch.bfloat16 if flat.w_lp is not None else None
             self._sync = GradSync(flat.g, comm_dtype=cd, force=self.force_collectives)
             # rank-0 parameters and buffers win (DDP constructor semantics, main_pretrain.py:418-420)
             self._sync.broadcast([flat.p])
+            flat.mark_changed()   # the broadcast wrote the masters behind the Parameters' version counters: the bf16 mirror must be recast
             self._broadcast_buffers()
             n_enc = len(self.module.encoder)
             self._ranges = {name: (lo, hi) for name, lo, hi in bucket_ranges(flat.slots, flat.names, n_enc, taper=True,

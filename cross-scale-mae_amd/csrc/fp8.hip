@@ -52,10 +52,11 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(long long rows, int cols
     for (long long r = blockIdx.x; r < rows; r += gridDim.x)
       for (int c = threadIdx.x; c < cv; c += blockDim.x) {
         f4_t v = ld4<T>(src + r * ld + c * 4);
-        seen = fmaxf(seen, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float a = fabsf(v[k]); seen = fmaxf(seen, a == a ? a : INFINITY); }   // NaN / Inf -> an amax of +Inf (the next step's scale is NaN: the loss gate trips)
         v *= scale;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], -fmax), fmax);
+        for (int k = 0; k < 4; ++k) v[k] = v[k] != v[k] ? v[k] : fminf(fmaxf(v[k], -fmax), fmax);   // (NaN is not clamped away)
         *reinterpret_cast<unsigned*>(dst + r * ldd + c * 4) = pack4_fp8<FMT>(v);
       }
     if (amax_next) {   // one atomic per workgroup (same-address atomics serialise in L2)
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(long long rows, int cols
         if (c0 + cc < cols && r0 + r4 < rows) {
           f4_t v = f4_t{tile[r4][cc], tile[r4 + 1][cc], tile[r4 + 2][cc], tile[r4 + 3][cc]} * scale;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], -fmax), fmax);
+          for (int k = 0; k < 4; ++k) v[k] = v[k] != v[k] ? v[k] : fminf(fmaxf(v[k], -fmax), fmax);
           *reinterpret_cast<unsigned*>(dst + (long long)(c0 + cc) * ldd + r0 + r4) = pack4_fp8<FMT>(v);
         }
       }

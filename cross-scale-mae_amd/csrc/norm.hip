@@ -15,7 +15,12 @@ __device__ __forceinline__ float fp8_emit_scale(const Fp8Emit& e, int lane, floa
 __device__ __forceinline__ unsigned fp8_pack4(f4_t v, float scale, float qmax, int fmt, float& seen) {
   int p = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { seen = fmaxf(seen, fabsf(v[k])); v[k] = fminf(fmaxf(v[k] * scale, -qmax), qmax); }
+  for (int k = 0; k < 4; ++k) {   // non-finite values are not hidden: NaN passes through the clamp, NaN / Inf record an amax of +Inf (next step: scale 0 x Inf = NaN -> the loss gate trips)
+    const float a = fabsf(v[k]);
+    seen = fmaxf(seen, a == a ? a : INFINITY);
+    const float q = v[k] * scale;
+    v[k] = q != q ? q : fminf(fmaxf(q, -qmax), qmax);
+  }
   if (fmt == 0) { p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true); }
   else { p = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], p, true); }
   return (unsigned)p;

@@ -85,8 +85,8 @@ def get_args_parser():
     p.add_argument("--synthetic_len", type=int, default=64, help="iterations per epoch of the synthetic loader")
     p.add_argument("--input_channels", type=int, default=None, help="bands of the synthetic loader / model (reference constructors default to 3)")
     p.add_argument("--honor_start_epoch", action="store_true", help="start the epoch loop at --start_epoch / the resumed epoch")
-    p.add_argument("--grad_comm_dtype", type=str, default="auto", choices=["auto", "fp32", "bf16"],
-                   help="RCCL gradient payload; auto = bf16 under autocast (the bf16 MFMA path), fp32 otherwise")
+    p.add_argument("--grad_comm_dtype", type=str, default="fp32", choices=["auto", "fp32", "bf16"],
+                   help="RCCL gradient payload: fp32 (default: what the reference's DDP exchanges), bf16 (half the xGMI bytes; opt-in), auto = bf16 when the engine computes in bf16 / fp8")
     return p
 
 

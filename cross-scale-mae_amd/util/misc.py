@@ -213,6 +213,13 @@ def clip_grad_norm_(parameters, max_norm):
             # every parameter of the model that has a gradient must be in the call (the buffer is normed as a whole)
             if flat is not None and views != sum(1 for q in flat.params.values() if q.grad is not None):
                 flat = None
+            # The buffer is normed as a whole, and the engine writes dW / db of every layer whether or not its Parameter is frozen (it only
+            # declines to hand the view to `.grad`): with a user-frozen parameter the flat norm would include gradients that
+            # torch.nn.utils.clip_grad_norm_ — and the reference — leave out.  Slots that are never written (the sin-cos tables, the
+            # discarded encoder_norm) hold zeros and are harmless.
+            if flat is not None and any(not q.requires_grad and not (n.endswith("pos_embed") or n.startswith("encoder_norm."))
+                                        for n, q in flat.params.items()):
+                flat = None
     if flat is None:
         if max_norm is None:
             return get_grad_norm_(params)

@@ -27,7 +27,7 @@ extern "C" {
 
 enum csmae_status { CSMAE_OK = 0, CSMAE_ERR_ARG = -1, CSMAE_ERR_LAUNCH = -2, CSMAE_ERR_UNSUPPORTED = -3 };
 enum csmae_epilogue { CSMAE_EPI_NONE = 0, CSMAE_EPI_GELU = 1, CSMAE_EPI_RESID = 2, CSMAE_EPI_DGELU = 3, CSMAE_EPI_ATOMIC = 4, CSMAE_EPI_SPLIT = 5,
-                      CSMAE_EPI_GELU_Q8 = 6, CSMAE_EPI_DGELU_Q8 = 7 /* bf16 path: aux = gelu'(x) as one byte per element, q = round((g + 0.13) * 255 / 1.26) */ };
+                      CSMAE_EPI_GELU_Q8 = 6, CSMAE_EPI_DGELU_Q8 = 7 /* bf16 path: aux = gelu'(x) as one byte per element, q = round(200 g + 26): g = 0 and 1 are codes 26 and 226 exactly */ };
 enum csmae_loss { CSMAE_LOSS_MSE = 0, CSMAE_LOSS_L2 = 1, CSMAE_LOSS_MAE = 2, CSMAE_LOSS_L1 = 3, CSMAE_LOSS_BCE = 4 };
 
 const char* csmae_last_error(void);

@@ -663,6 +663,62 @@ def g_fullsize(tags=None):
     np.savez_compressed(os.path.join(OUT, "fullsize.npz"), **d)
     json.dump(meta, open(os.path.join(OUT, "fullsize.json"), "w"), indent=1)
 
+N128_SMALL = ("cls_token", "mask_token", "decoder_pred.bias", "predictor.1.weight", "predictor.1.bias", "decoder_norm.weight", "encoder.11.norm2.bias",
+              "encoder.0.attn.qkv.bias", "decoder.0.mlp.fc2.bias", "patch_embed.proj.bias")
+
+
+def n128_inputs():
+    """Seeded inputs of the N = 128 fixture (same recipe as tests/test_model_gpu.py::test_full_size_vitb_224_n128_*: nothing stored)."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(128, 3, 224, 224, generator=g)
+    return x, [torch.rand(128, 196, generator=g), torch.rand(128, 196, generator=g)]
+
+
+def g_fullsize_n128():
+    """BASELINE.json configs[1] at the batch the bench runs: the REFERENCE's MAE_ViT_MsLdCeCd ViT-B/16 224^2 at N = 128 (BatchNorm over the
+    batch and the NT-Xent negatives couple the samples, so the N = 4 fixture cannot stand in for it), one forward + backward on CPU
+    (about 2 min on 8 threads, ~35 GB): the four loss terms, the mask (bit-packed), sum / sum of squares of every parameter gradient
+    and a few small gradients in full."""
+    geom = FULLSIZE["vitb16_224"][0]
+    torch.manual_seed(0)
+    with quiet():
+        m = models_mae.MAE_ViT_MsLdCeCd(**geom, input_size=224, patch_size="16", input_channels=3, loss="mse", device="cpu")
+    m.train()
+    imgs, noise = n128_inputs()
+    rec = dict(recon=[], ce=[], cd=[])
+    ofl = m.forward_loss
+    m.forward_loss = lambda *a, _o=ofl, **k: (lambda r: (rec["recon"].append(float(r)), r)[1])(_o(*a, **k))
+    ocd = getattr(m, "_MAE_ViT_MsLdCeCd__forward_loss_cd")
+    setattr(m, "_MAE_ViT_MsLdCeCd__forward_loss_cd", lambda *a, _o=ocd, **k: (lambda r: (rec["cd"].append(float(r)), r)[1])(_o(*a, **k)))
+    orig_nt = ref_contrast.NTXentLoss.forward
+    ref_contrast.NTXentLoss.forward = lambda self, a, b: (lambda r: (rec["ce"].append(float(r)), r)[1])(orig_nt(self, a, b))
+    draws = []
+    try:
+        torch.manual_seed(4242)
+        with record_rand(draws, inject=noise):
+            out = m(imgs, mask_ratio=0.75, return_embeds=True)
+    finally:
+        ref_contrast.NTXentLoss.forward = orig_nt
+    out[0].backward()
+    assert len(draws) == 2 and torch.equal(draws[0], noise[0]) and torch.equal(draws[1], noise[1])
+    grads = {n: q.grad for n, q in m.named_parameters() if q.grad is not None}
+    names = sorted(grads)
+    d = dict(mask_bits=np.packbits(npy(out[2]).astype(np.uint8), axis=1), gradnames=np.array(names),
+             gradsq=np.array([grads[n].double().pow(2).sum().item() for n in names]),
+             gradsum=np.array([grads[n].double().sum().item() for n in names]), pred_head=npy(out[1][:2, :2, :48]))
+    for n in N128_SMALL:
+        d["g_" + n] = npy(grads[n])
+    meta = dict(geom=geom, input_size=224, patch=16, channels=3, N=128, loss=float(out[0]), recon=rec["recon"], ce=rec["ce"][0], cd=rec["cd"][0],
+                box=[int(v) for v in ref_stubs.RandomResizedCrop.last_box], imgs_checksum=checksum(imgs)[:3],
+                noise_checksum=[checksum(noise[0])[:3], checksum(noise[1])[:3]],
+                pred_sum=[out[1].double().sum().item(), out[1].double().abs().sum().item()],
+                nograd=[n for n, q in m.named_parameters() if q.requires_grad and q.grad is None],
+                weights={k: checksum(v)[:3] for k, v in m.state_dict().items() if k in FULLSIZE_WEIGHTS})
+    _print(f"fullsize n128: loss {float(out[0]):.6f} recon {rec['recon']} ce {rec['ce'][0]:.6f} cd {rec['cd'][0]:.6f} box {meta['box']}")
+    np.savez_compressed(os.path.join(OUT, "fullsize_n128.npz"), **d)
+    json.dump(meta, open(os.path.join(OUT, "fullsize_n128.json"), "w"), indent=1)
+
+
 def main():
     torch.set_num_threads(8)
     with quiet():
@@ -678,6 +734,7 @@ def main():
     g_model_micro()
     g_vitb()
     g_fullsize()
+    g_fullsize_n128()
     for f in sorted(os.listdir(OUT)):
         _print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
 

@@ -502,23 +502,35 @@ def test_fp8_step_vs_reference_and_oracle(tag):
     assert all(torch.isfinite(p).all() for p in m.parameters())
 
 
-def test_full_size_vitb_224_n128_properties():
-    """BASELINE.json configs[1] at full size (ViT-B/16 MsLdCeCd, 224^2, 128 images, bf16 MFMA path) through properties that need no
-    oracle run: masking indices are permutations in noise order with exactly L - keep masked patches per row; the step is deterministic
-    (two runs on the same draws: bit-identical loss and gradients — every reduction is ordered); the total is the sum of its terms;
-    the backward is exactly linear in the incoming gradient for a power-of-two factor; and the fp32 engine — itself pinned to the
-    reference at this geometry by test_fullsize_geometry_vs_reference_and_oracle — agrees within BF16_LOSS_RTOL / BF16_GRAD_COS."""
+def test_full_size_vitb_224_n128_vs_reference():
+    """BASELINE.json configs[1] at full size (ViT-B/16 MsLdCeCd, 224^2, 128 images, bf16 MFMA path) against the REFERENCE run at this very
+    batch (tests/golden/fullsize_n128.*, oracle/gen_golden.py:g_fullsize_n128 — BatchNorm over the batch and the NT-Xent negatives couple
+    the samples, so the N = 4 fixture cannot stand in): total loss and its four terms within BF16_LOSS_RTOL, the masks bit-exact, every
+    parameter gradient's norm within 2 % of the reference's, the small gradients the fixture holds in full at BF16_GRAD_COS.  Plus what
+    needs no yardstick: masking indices are permutations in noise order; the step is deterministic (two runs on the same draws:
+    bit-identical loss and gradients — every reduction is ordered); the total is the sum of its terms; the backward is exactly linear
+    in the incoming gradient for a power-of-two factor."""
+    import json
     import models_mae
+    from fullsize_util import G, checksum
+    meta = json.load(open(os.path.join(G, "fullsize_n128.json")))
+    ref = np.load(os.path.join(G, "fullsize_n128.npz"), allow_pickle=False)
     torch.manual_seed(0)
-    m = models_mae.mae_vit_base_MsLdCeCd(input_size=224, patch_size="16", loss="mse", device="cuda").cuda().train()
+    m = models_mae.mae_vit_base_MsLdCeCd(input_size=224, patch_size="16", loss="mse", device="cuda")
+    sd = m.state_dict()
+    for k, c in meta["weights"].items():
+        assert np.allclose(checksum(sd[k].cpu()), c, rtol=1e-12, atol=1e-9), f"seeded init of {k} differs from the reference's"
+    m = m.cuda().train()
     N, L, keep = 128, 196, 49
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(N, 3, 224, 224, generator=g).cuda()
+    x = torch.randn(N, 3, 224, 224, generator=g)
     noise = [torch.rand(N, L, generator=g), torch.rand(N, L, generator=g)]
-    draws = dict(noise=noise, box=(31, 17, 140, 150))
+    assert np.allclose(checksum(x), meta["imgs_checksum"], rtol=1e-12, atol=1e-9) and np.allclose(checksum(noise[1]), meta["noise_checksum"][1], rtol=1e-12, atol=1e-9)
+    x = x.cuda()
+    draws = dict(noise=noise, box=tuple(meta["box"]))
     names = ("decoder_pred.weight", "encoder.0.attn.qkv.weight", "decoder.3.mlp.fc1.weight", "patch_embed.proj.weight", "cls_token", "predictor.1.weight")
 
-    def run(dtype, scale=1.0):
+    def run(dtype, scale=1.0, every=False):
         m.compute_dtype = dtype
         m.zero_grad(set_to_none=True)
         m._test_draws = dict(draws)
@@ -526,9 +538,33 @@ def test_full_size_vitb_224_n128_properties():
         (loss * scale).backward()
         eng = m._engines[dtype]
         params = dict(m.named_parameters())
-        return (loss.detach().clone(), mask.clone(), eng.ws.ids_restore.clone(), eng.ws.losses.clone(), {n: params[n].grad.detach().clone() for n in names})
+        keep_names = [n for n, q in params.items() if q.grad is not None] if every else names
+        return (loss.detach().clone(), mask.clone(), eng.ws.ids_restore.clone(), eng.ws.losses.clone(), {n: params[n].grad.detach().clone() for n in keep_names})
 
-    la, mask, ids, terms, ga = run(torch.bfloat16)
+    la, mask, ids, terms, gall = run(torch.bfloat16, every=True)
+    ga = {n: gall[n] for n in names}
+    # ---- against the reference at N = 128
+    t = terms.double().cpu()
+    assert abs(float(la) - meta["loss"]) <= BF16_LOSS_RTOL * abs(meta["loss"]), (float(la), meta["loss"])
+    # ws.losses: [0] total [1] recon orig [2] recon crop [3] cross-decoder [4] contrastive [5] latent (unused by this variant)
+    for got, want, what in ((t[1], meta["recon"][0], "recon orig"), (t[2], meta["recon"][1], "recon crop"), (t[3], meta["cd"], "cross-decoder"), (t[4], meta["ce"], "contrastive")):
+        assert abs(float(got) - want) <= 2 * BF16_LOSS_RTOL * abs(want), (what, float(got), want)
+    assert np.array_equal(np.packbits(mask.cpu().numpy().astype(np.uint8), axis=1), ref["mask_bits"]), "random_masking mask differs from the reference's at N = 128"
+    rnames = [str(n) for n in ref["gradnames"]]
+    assert set(rnames) == set(gall), set(rnames) ^ set(gall)
+    worst = 0.0
+    for n, sq in zip(rnames, ref["gradsq"]):
+        mine = float(gall[n].double().pow(2).sum())
+        if sq > 1e-20:
+            worst = max(worst, abs(mine ** 0.5 / sq ** 0.5 - 1.0))
+            assert abs(mine ** 0.5 / sq ** 0.5 - 1.0) < 2e-2, (n, mine, float(sq))
+    for k in ref.files:
+        if k.startswith("g_"):
+            n = k[2:]
+            r = torch.from_numpy(ref[k]).double().flatten()
+            cos = torch.nn.functional.cosine_similarity(gall[n].double().cpu().flatten(), r, dim=0)
+            assert cos > BF16_GRAD_COS, (n, float(cos))
+    # ---- properties
     lb, _, ids_b, _, gb = run(torch.bfloat16)
     assert torch.equal(la, lb) and torch.equal(ids, ids_b) and all(torch.equal(ga[n], gb[n]) for n in names)        # deterministic
     assert torch.isfinite(la) and all(torch.isfinite(v).all() for v in ga.values())
@@ -542,18 +578,10 @@ def test_full_size_vitb_224_n128_properties():
     assert bool((kept_max <= masked_min).all())
     assert torch.equal(ids, torch.argsort(torch.argsort(nz, dim=1, stable=True), dim=1, stable=True))                 # == the reference's double argsort
     # the total is the sum of the four terms (reconstruction of both views, cross-decoder, contrastive)
-    t = terms.double().cpu()
     assert abs(float(t[0]) - float(t[1] + t[2] + t[3] + t[4] + t[5])) < 1e-5 * abs(float(t[0]))
     # exact linearity of the backward pass for a power-of-two upstream gradient
     _, _, _, _, g2 = run(torch.bfloat16, scale=2.0)
     assert all(torch.equal(g2[n], 2.0 * ga[n]) for n in names)
-    # fp32 engine on the same draws
-    lf, _, ids_f, _, gf = run(torch.float32)
-    assert torch.equal(ids_f, ids)
-    assert abs(float(la) - float(lf)) <= BF16_LOSS_RTOL * abs(float(lf)), (float(la), float(lf))
-    for n in names:
-        cos = torch.nn.functional.cosine_similarity(ga[n].flatten().double(), gf[n].flatten().double(), dim=0)
-        assert cos > BF16_GRAD_COS, (n, float(cos))
 
 
 def test_metrics_ssim_on_gpu_match_oracle():
