@@ -28,6 +28,9 @@ _SIGNATURES = {
     "csmae_fp8_amax": [I, L, I, P, L, P, P],
     "csmae_fp8_quantize": [I, I, I, L, I, P, L, P, L, P, P, P, P],
     "csmae_gemm_fp8": [I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P, P, P, L, I, P, P, P, P],
+    "csmae_gemm_resid_stats": [L, L, L, P, L, P, L, P, L, P, P, L, P, L, P],
+    "csmae_gemm_lnfold": [L, L, L, P, L, P, L, P, L, P, P, P, L, I, F, P, P, I, P, L, P],
+    "csmae_ln_fold_weights": [I, I, P, P, P, P, P],
     "csmae_gemm_force_tile": [I],
     "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
@@ -39,9 +42,9 @@ _SIGNATURES = {
     "csmae_crop_resize": [L, I, P, P, P, P],
     "csmae_mask_sort": [L, I, I, P, P, P, P, P, P],
     "csmae_patch_gather": [I, L, I, I, I, I, I, P, P, P, P, L, P],
-    "csmae_embed_assemble": [I, L, I, I, P, P, P, P, P, P],
+    "csmae_embed_assemble": [I, L, I, I, P, P, P, P, P, P, P],
     "csmae_embed_assemble_bwd": [I, I, L, I, I, P, P, P, P],
-    "csmae_unshuffle_fwd": [I, L, I, I, I, P, P, P, P, P, P],
+    "csmae_unshuffle_fwd": [I, L, I, I, I, P, P, P, P, P, P, P],
     "csmae_unshuffle_bwd": [I, I, L, I, I, I, P, P, P, P, P],
     "csmae_rows_gather": [I, L, I, P, L, L, L, P, P],
     "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],
@@ -89,7 +92,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = sig
         fn.restype = c_int
-    if lib.csmae_abi_version() != 2:
+    if lib.csmae_abi_version() != 3:
         raise CsmaeError("libcsmae_hip ABI version mismatch")
     _lib = lib
     return lib

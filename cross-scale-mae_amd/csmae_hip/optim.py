@@ -116,6 +116,7 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp,
                       gate=flat.gate)
+            flat.raw_writes += 1   # the kernel wrote the masters (and the bf16 mirror) behind torch's version counters: the folded LayerNorm operands are stale
             self._dirty_steps = True
         return loss
 

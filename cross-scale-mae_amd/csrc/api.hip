@@ -21,4 +21,4 @@ int csmae_check_launch(const char* what) {
 }
 
 extern "C" const char* csmae_last_error(void) { return g_err; }
-extern "C" int csmae_abi_version(void) { return 2; }
+extern "C" int csmae_abi_version(void) { return 3; }
