@@ -908,9 +908,20 @@ class Engine:
             self.side = torch.cuda.Stream()
         self._ev_i, self._tog = 0, 0
         self._side_reads.clear()
+        zeroed = None
         if not accumulate:
-            self.flat.g.zero_()
-        ops.gate_accumulate(ws.losses, self.flat.gate, accumulate, st=st)
+            # The gradient clear (455 MB for ViT-B) runs on the weight-gradient stream, which is idle between the forward and the backward
+            # pass, beside the reconstruction head's backward on the main stream: every weight-gradient launch follows it in stream order,
+            # the main stream's own writers into the buffer (BatchNorm / LayerNorm / token gradients) wait for `zeroed` below.
+            if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN") or os.environ.get("CSMAE_ZERO_MAIN"):   # (CSMAE_ZERO_MAIN: A/B aid)
+                self.flat.g[: self.flat.total].zero_()
+            else:
+                self.side.wait_stream(self.main)
+                with torch.cuda.stream(self.side):
+                    self.flat.g[: self.flat.total].zero_()
+                zeroed = self._event()
+                zeroed.record(self.side)
+        ops.gate_accumulate(ws.losses, self.flat.gate, accumulate, st=st)   # (the gate slot sits behind `total`: written here, not cleared)
         ws.gout.copy_(gout.reshape(1).to(torch.float32))
         kind, npx = c["loss"], c["norm_pix"]
         # reconstruction head
@@ -923,6 +934,8 @@ class Engine:
                            B2, N, c["C"], c["S"], c["p"], extra=extra, st=st)
         self._dw(ws.dpred_lp, ws.emb_lp, "decoder_pred")
         ops.gemm(ws.dpred_lp, self._w_pred(), ws.demb, trans_b=True, st=st)
+        if zeroed is not None:
+            self.main.wait_event(zeroed)
         if self.has_pred:
             kcd = c["loss_cd"]
             bn = "predictor.1."

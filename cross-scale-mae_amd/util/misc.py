@@ -172,6 +172,8 @@ def init_distributed_mode(args):
     if use_gpu:
         torch.cuda.set_device(args.gpu)
     args.dist_backend = "nccl" if use_gpu else "gloo"
+    # (RCCL's kernels run beside GEMM workgroups that each own a whole CU: a high-priority queue lets a collective take the next CU that frees up)
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
     print(f"| distributed init (rank {args.rank}): {args.dist_url}, gpu {args.gpu}, world size {args.world_size}", flush=True)
     dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size, rank=args.rank)
     dist.barrier()

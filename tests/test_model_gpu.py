@@ -652,7 +652,8 @@ def test_viz_prepare_model_and_run_one_image(tmp_path):
 
 @pytest.mark.parametrize("variant,S,p,N,mask_ratio", [("MAE_ViT_MsLdCeCd", 96, 16, 3, 0.5), ("MAE_ViT_MsLdLeCd", 112, 14, 2, 0.75),
                                                       ("MAE_ViT_Baseline", 80, 16, 1, 0.9), ("MAE_ViT_MsLd", 128, 8, 2, 0.6),
-                                                      ("MAE_ViT_MsLdCd", 48, 16, 5, 0.25)])
+                                                      ("MAE_ViT_MsLdCd", 48, 16, 5, 0.25),
+                                                      ("MAE_ViT_MsLdCeCd", 320, 16, 2, 0.75)])   # 401 decoder tokens: beyond the LDS-resident attention kernels (any-length fallback)
 def test_odd_geometries_fp32_vs_oracle(variant, S, p, N, mask_ratio):
     """Geometries away from the benchmark's: 36 / 64 / 25 / 256 / 9 patches, 14- and 8-pixel patches (P = 588, 192), one sample, keep
     ratios 0.5 / 0.1 / 0.75, odd batch sizes — whole step in fp32 against the oracle on the same weights, noise and crop box."""
@@ -691,7 +692,8 @@ def test_odd_geometries_fp32_vs_oracle(variant, S, p, N, mask_ratio):
 
 
 @pytest.mark.parametrize("variant,S,p,N,mask_ratio", [("MAE_ViT_MsLdCeCd", 96, 16, 3, 0.5), ("MAE_ViT_MsLdLeCd", 112, 14, 2, 0.75),
-                                                      ("MAE_ViT_Baseline", 80, 16, 1, 0.9), ("MAE_ViT_MsLd", 128, 8, 2, 0.6)])
+                                                      ("MAE_ViT_Baseline", 80, 16, 1, 0.9), ("MAE_ViT_MsLd", 128, 8, 2, 0.6),
+                                                      ("MAE_ViT_MsLdCeCd", 320, 16, 2, 0.75)])
 def test_odd_geometries_bf16_tracks_fp32(variant, S, p, N, mask_ratio):
     """The same odd geometries through the MFMA path (ragged M / N / K tiles, P = 588, one sample): loss within 2e-2 of the fp32 engine,
     gradient cosine > 0.98 on every parameter that has one."""

@@ -229,6 +229,11 @@ def test_bench_two_ranks_plumbing_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0 and np.isfinite(d["loss"]) and "cpu_baseline" not in d
     assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-2 * d["value"]
+    # the line verifies itself: both ranks took part, the replicas hold identical weights after the timed steps,
+    # the ranks saw different data (different losses), every bucket went out, fp32 payload by default
+    dp = d["data_parallel"]
+    assert dp["ranks_seen"] == 2 and dp["weights_checksum_spread"] == 0.0 and dp["grad_payload"] == "fp32" and dp["buckets_per_step"] >= 3
+    assert dp["ms_per_step_min"] <= dp["ms_per_step_max"] == d["ms_per_step"] and dp["loss_min"] < dp["loss_max"]
 
 
 MICRO6 = dict(dim_model=128, encoder_num_layers=2, encoder_num_heads=2, decoder_embed_dim=64, decoder_num_layers=2, decoder_num_heads=2)
