@@ -8,6 +8,17 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result
 
 all: $(LIB)
 
+# the content hash of csrc/ is baked into the library (csmae_source_hash()): a profile or a bench line can then say which sources the
+# kernels it measured were built from.  build/obj/src_hash.txt is rewritten only when the hash moves, so api.o rebuilds exactly then.
+SRC_HASH := $(shell python3 tools/csrc_hash.py)
+build/obj/src_hash.txt: $(SRC) $(PKG)/csrc/common.h
+	@mkdir -p build/obj
+	@echo '$(SRC_HASH)' | cmp -s - $@ || echo '$(SRC_HASH)' > $@
+
+build/obj/api.o: $(PKG)/csrc/api.hip $(PKG)/csrc/common.h build/obj/src_hash.txt
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -DCSMAE_SRC_HASH='"$(SRC_HASH)"' -c $< -o $@
+
 build/obj/%.o: $(PKG)/csrc/%.hip $(PKG)/csrc/common.h
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -56,14 +56,9 @@ def build(device, batch, world, loss="mse", preset="base"):
 
 def csrc_hash():
     """Content hash of the kernel sources: what a committed PMC profile is valid for."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "cross-scale-mae_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash as h
+    return h()
 
 
 def log(msg):
@@ -147,6 +142,8 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     import csmae_hip
     csmae_hip.load()
+    if csmae_hip.source_hash() != csrc_hash():
+        log(f"WARNING: libcsmae_hip.so was built from csrc {csmae_hip.source_hash()[:16]}, the tree holds {csrc_hash()[:16]} (stale build?)")
 
     factory, size, patch, chans, pbatch, gflop = PRESETS[a.preset]
     if a.batch is None:
@@ -235,7 +232,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
-        if t.get("csrc_sha256") == csrc_hash():
+        if t.get("csrc_sha256") == csrc_hash() == csmae_hip.source_hash():
             traffic = {"bytes_per_launch": int(t["gemm_mb_per_launch"] * 2 ** 20), "step_hbm_gb": t["step_hbm_gb"], "source": t["source"], "csrc_sha256": t["csrc_sha256"][:16]}
         else:
             log("profiles/pmc_traffic.json was measured on different kernel sources: roofline.traffic = null (re-run tools/pmc_traffic.py)")
@@ -254,7 +251,7 @@ def main():
                        "MAE_ViT_MsLdCeCd ViT-B/16, 224^2 two-scale crops, mask 0.75, AdamW, full optimizer step",
                        "loss": a.loss, "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [chans, size, size], "parallelism": f"dp{world}",
                        "headline_config": bool(scale)},
-            "loss": round(final_loss, 5),
+            "loss": round(final_loss, 5), "library_source_sha256": csmae_hip.source_hash()[:16],
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic if (a.preset == "base" and a.dtype == "bf16" and scale) else None, "algorithmic_gflop_per_image": gflop, "dominant_kernel": kernel},
         }

@@ -87,6 +87,7 @@ def load():
                          "the MI355X path has no CPU/eager fallback")
     lib = ctypes.CDLL(LIB_PATH)
     lib.csmae_last_error.restype = ctypes.c_char_p
+    lib.csmae_source_hash.restype = ctypes.c_char_p
     lib.csmae_abi_version.restype = c_int
     for name, sig in _SIGNATURES.items():
         fn = getattr(lib, name)
@@ -104,4 +105,9 @@ def check(rc: int, what: str = ""):
 
 
 def exported_symbols():
-    return ["csmae_last_error", "csmae_abi_version"] + list(_SIGNATURES)
+    return ["csmae_last_error", "csmae_abi_version", "csmae_source_hash"] + list(_SIGNATURES)
+
+
+def source_hash() -> str:
+    """sha256 of the kernel sources the loaded library was built from."""
+    return load().csmae_source_hash().decode()

@@ -22,3 +22,7 @@ int csmae_check_launch(const char* what) {
 
 extern "C" const char* csmae_last_error(void) { return g_err; }
 extern "C" int csmae_abi_version(void) { return 3; }
+#ifndef CSMAE_SRC_HASH
+#define CSMAE_SRC_HASH "unknown"
+#endif
+extern "C" const char* csmae_source_hash(void) { return CSMAE_SRC_HASH; }   // sha256 of csrc/ at build time (tools/csrc_hash.py)

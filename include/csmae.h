@@ -32,6 +32,7 @@ enum csmae_loss { CSMAE_LOSS_MSE = 0, CSMAE_LOSS_L2 = 1, CSMAE_LOSS_MAE = 2, CSM
 
 const char* csmae_last_error(void);
 int csmae_abi_version(void);
+const char* csmae_source_hash(void);   /* sha256 of the kernel sources the library was built from (tools/csrc_hash.py): profiles are keyed to it */
 
 /* ---- dense contractions: nn.Linear of timm Block / decoder_embed / decoder_pred / predictor and their backward
  * (timm 0.4.12 Attention.qkv/.proj, Mlp.fc1/.fc2 — call sites models_mae/MAE_ViT_Baseline.py:160-188,270,295;

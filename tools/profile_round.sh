@@ -3,13 +3,22 @@
 # serialised), HBM-traffic PMC passes, preset lines.  usage: tools/profile_round.sh TAG
 tag=$1; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
+# a profile names the kernel sources it measured: refuse to run when the library was not built from the sources in the tree
+python -c "
+import sys
+sys.path.insert(0, 'cross-scale-mae_amd'); sys.path.insert(0, 'tools')
+import csmae_hip
+from csrc_hash import csrc_hash
+lib, src = csmae_hip.source_hash(), csrc_hash()
+sys.exit(0 if lib == src else f'libcsmae_hip.so was built from csrc {lib[:16]}, the tree holds {src[:16]}: rebuild (make) before profiling')
+" || exit 1
 timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
 python tools/rocpd_stats.py $(find /tmp/prof_$tag -name '*.db' | head -1) $out/step_kernel_stats.txt > /dev/null
 python tools/step_timeline.py $(find /tmp/prof_$tag -name '*.db' | head -1) > $out/step_timeline.txt 2>&1
 ( cd /tmp && CSMAE_DW_MAIN=1 CSMAE_FWD_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profs_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
 python tools/rocpd_stats.py $(find /tmp/profs_$tag -name '*.db' | head -1) $out/step_serialised_kernel_stats.txt > /dev/null
-bash tools/pmc_round.sh $tag > /dev/null 2>&1
+bash tools/roofline_round.sh $tag > /dev/null 2>&1   # per-kernel HBM GB/s + MFMA utilisation (kernel_roofline.txt) and the HBM traffic table / pmc_traffic.json
 for p in large large4; do timeout 600 python bench.py --preset $p --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out/bench_presets.txt; done
 for d in bf16 fp8; do timeout 600 python bench.py --preset huge14 --dtype $d --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out/bench_presets.txt; done
 cp $out/pmc_traffic.json profiles/pmc_traffic.json   # (on the GPU box only: the bench line below then carries roofline.traffic for these sources; copy it into profiles/ by hand afterwards)
