@@ -153,7 +153,7 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 // Phi(x) for bf16 outputs without the reciprocal and the sign select of the A&S form: Phi = 0.5 + xc * P(xc^2) with xc = clamp(x, +-3.5)
 // and an odd minimax polynomial constrained to reach exactly +-0.5 at the clamp (Phi saturates at 0 / 1 beyond; max |Phi error| 2.3e-4,
 // max |gelu error| 8e-4 at x = 3.5 where a bf16 ulp is 1.6e-2).  The fc1 epilogue is VALU-bound: per pair of elements this is
-// 16 packed / scalar ops + 2 transcendentals (the Gaussian density of gelu') instead of 21 + 4 — and since round 3 no transcendental at all (below).
+// 16 packed / scalar ops + 2 transcendentals (the Gaussian density of gelu') instead of 21 + 4.
 __device__ __forceinline__ void gelu_both2_fast(f2_t x, f2_t& h, f2_t& gp) {
   const f2_t xc = {__builtin_amdgcn_fmed3f(x[0], -3.5f, 3.5f), __builtin_amdgcn_fmed3f(x[1], -3.5f, 3.5f)};
   const f2_t u = xc * xc;
@@ -163,17 +163,10 @@ __device__ __forceinline__ void gelu_both2_fast(f2_t x, f2_t& h, f2_t& gp) {
   poly = poly * u + -6.439825892e-02f;
   poly = poly * u + 3.980685472e-01f;
   const f2_t phi = xc * poly + 0.5f;                                     // Phi(x)
+  const f2_t xx = x * x * -0.72134752f;
+  const f2_t e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};   // exp(-x^2/2)
   h = x * phi;
-  // gelu'(x) = Phi(x) + x phi(x) the same way: 0.5 + xc * Q(xc^2), an odd minimax polynomial on the same clamp (max |error| 1.5e-3, at and
-  // beyond the clamp too: the fit ends 1.3e-3 above 1 where the true value decays from 1.0028 to 1).  The derivative is stored as an 8-bit
-  // code with a 5e-3 step, and the fc1 epilogue is bound by its VALU work (20 k of a tile's 45 k clocks, two waves sharing a SIMD): the two
-  // exp2 of the Gaussian density were 8 of its ~28 issue slots per pair of elements, these are 6.
-  f2_t q = u * -6.524684638e-06f + 2.852716486e-04f;
-  q = q * u + -5.071030628e-03f;
-  q = q * u + 4.739125433e-02f;
-  q = q * u + -2.499994663e-01f;
-  q = q * u + 7.918828500e-01f;
-  gp = xc * q + 0.5f;
+  gp = x * 0.39894228f * e + phi;
 }
 template <> __device__ __forceinline__ void gelu_both4<bf16_t>(f4_t x, f4_t& h, f4_t& gp) {
   f2_t h0, g0, h1, g1;
