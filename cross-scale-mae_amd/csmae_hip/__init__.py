@@ -27,6 +27,7 @@ _SIGNATURES = {
     "csmae_gemm_dw_group": [I, I, L, P, P, P, P, P, P, P, P, I, P, L, P],
     "csmae_fp8_amax": [I, L, I, P, L, P, P],
     "csmae_fp8_quantize": [I, I, I, L, I, P, L, P, L, P, P, P, P],
+    "csmae_fp8_weights": [I, P, P, P, P, P, P, P],
     "csmae_gemm_fp8": [I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P, P, P, L, I, P, P, P, P],
     "csmae_gemm_resid_stats": [L, L, L, P, L, P, L, P, L, P, P, L, P, L, P],
     "csmae_gemm_lnfold": [L, L, L, P, L, P, L, P, L, P, P, P, L, I, F, P, P, I, P, L, P],

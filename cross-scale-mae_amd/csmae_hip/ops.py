@@ -160,6 +160,11 @@ def fp8_quantize(src, dst, amax, dq, fmt=FP8_E4M3, transpose=False, amax_next=No
 FP8_SLOTS = 64   # an amax is 64 partial maxima (see csrc/fp8.hip)
 
 
+def fp8_weights(desc, p, w8, w8t, amax, dq, st=None):
+    """All fp8 weight mirrors in three launches: desc int64 [count, 3] = (offset in p / w8 / w8t, out, in); amax [count, 64] zeroed, dq [count]."""
+    check(load().csmae_fp8_weights(desc.shape[0], _p(desc), _p(p), _p(w8), _p(w8t), _p(amax), _p(dq), st if st is not None else stream()), "csmae_fp8_weights")
+
+
 def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI_NONE, aux=None, resid=None, emit=None, st=None):
     """out[M,N] = dq_a * dq_b * a8[M,K] b8[N,K]^T (+ epilogue): both operands K-contiguous fp8 bytes (uint8 tensors).
     emit = (q_out uint8 [M,N], fmt, amax_prev [64], amax_next [64], dq [1]): the epilogue also writes `out` as fp8 bytes for the next GEMM."""

@@ -13,7 +13,7 @@ __device__ __forceinline__ float fp8_amax_read(const float* slots) { return wave
 #define FP8_E5M2_MAX 57344.0f
 
 template <typename T>
-__global__ __launch_bounds__(256) void fp8_amax_kernel(long long rows, int cols, const T* __restrict__ src, long long ld, float* __restrict__ amax) {
+__device__ __forceinline__ void fp8_amax_body(long long rows, int cols, const T* __restrict__ src, long long ld, float* __restrict__ amax) {
   __shared__ float red[4];
   const int cv = cols >> 2;
   float m = 0.f;
@@ -30,6 +30,10 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(long long rows, int cols,
     atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & (FP8_SLOTS - 1)), __float_as_uint(m));   // (non-negative floats order like their bit patterns)
   }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(long long rows, int cols, const T* __restrict__ src, long long ld, float* __restrict__ amax) {
+  fp8_amax_body<T>(rows, cols, src, ld, amax);
+}
 
 template <int FMT> __device__ __forceinline__ unsigned pack4_fp8(f4_t v) {
   int p = 0;
@@ -40,8 +44,8 @@ template <int FMT> __device__ __forceinline__ unsigned pack4_fp8(f4_t v) {
 
 // dst[r][c] (TR = 0) or dst[c][r] (TR = 1: the pre-transposed weight mirror the dX products read) = fp8(src[r][c] * scale)
 template <typename T, int FMT, int TR>
-__global__ __launch_bounds__(256) void fp8_quant_kernel(long long rows, int cols, const T* __restrict__ src, long long ld, unsigned char* __restrict__ dst,
-                                                        long long ldd, const float* __restrict__ amax, float* __restrict__ dq, float* __restrict__ amax_next) {
+__device__ __forceinline__ void fp8_quant_body(long long rows, int cols, const T* __restrict__ src, long long ld, unsigned char* __restrict__ dst,
+                                               long long ldd, const float* __restrict__ amax, float* __restrict__ dq, float* __restrict__ amax_next) {
   const float fmax = FMT == 0 ? FP8_E4M3_MAX : FP8_E5M2_MAX;
   const float am = fp8_amax_read(amax);
   float seen = 0.f;   // delayed scaling: max|x| of THIS tensor, for the next step's scale (values beyond the old amax saturate)
@@ -94,6 +98,34 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(long long rows, int cols
       }
     }
   }
+}
+
+template <typename T, int FMT, int TR>
+__global__ __launch_bounds__(256) void fp8_quant_kernel(long long rows, int cols, const T* __restrict__ src, long long ld, unsigned char* __restrict__ dst,
+                                                        long long ldd, const float* __restrict__ amax, float* __restrict__ dq, float* __restrict__ amax_next) {
+  fp8_quant_body<T, FMT, TR>(rows, cols, src, ld, dst, ldd, amax, dq, amax_next);
+}
+
+// ---- all fp8 weight mirrors of a model in three launches (blockIdx.y = weight): per-tensor amax of the fp32 masters, W8 [out][in] (e4m3) for
+// the forward products, W8^T [in][out] for dX.  desc[k] = {offset of weight k in the flat parameter buffer (= in both byte mirrors), out, in};
+// amax [count][64] (zeroed by the caller), dq [count].  Replaces four launches per weight and step (640 for ViT-H/14: ~2 % of its fp8 step).
+__global__ __launch_bounds__(256) void fp8_weights_amax_kernel(const long long* __restrict__ desc, const float* __restrict__ p, float* __restrict__ amax) {
+  const long long* d = desc + blockIdx.y * 3;
+  fp8_amax_body<float>(d[1], (int)d[2], p + d[0], d[2], amax + (long long)blockIdx.y * FP8_SLOTS);
+}
+template <int TR>
+__global__ __launch_bounds__(256) void fp8_weights_quant_kernel(const long long* __restrict__ desc, const float* __restrict__ p, unsigned char* __restrict__ w8,
+                                                                const float* __restrict__ amax, float* __restrict__ dq) {
+  const long long* d = desc + blockIdx.y * 3;
+  fp8_quant_body<float, 0, TR>(d[1], (int)d[2], p + d[0], d[2], w8 + d[0], TR ? d[1] : d[2], amax + (long long)blockIdx.y * FP8_SLOTS, dq + blockIdx.y, nullptr);
+}
+extern "C" int csmae_fp8_weights(int count, const long long* desc, const float* p, void* w8, void* w8t, float* amax, float* dq, void* stream) {
+  CSMAE_REQUIRE(count > 0 && desc && p && w8 && w8t && amax && dq, "csmae_fp8_weights: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fp8_weights_amax_kernel, dim3(64, count), dim3(256), 0, st, desc, p, amax);
+  hipLaunchKernelGGL(fp8_weights_quant_kernel<0>, dim3(64, count), dim3(256), 0, st, desc, p, (unsigned char*)w8, amax, dq);
+  hipLaunchKernelGGL(fp8_weights_quant_kernel<1>, dim3(128, count), dim3(256), 0, st, desc, p, (unsigned char*)w8t, amax, dq);
+  return csmae_check_launch("csmae_fp8_weights");
 }
 
 extern "C" int csmae_fp8_amax(int in_dtype, long long rows, int cols, const void* src, long long ld, float* amax, void* stream) {

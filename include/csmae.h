@@ -68,6 +68,10 @@ int csmae_gemm_dw_group(int dtype, int count, long long K, const void* const* dY
 int csmae_fp8_amax(int in_dtype, long long rows, int cols, const void* src, long long ld, float* amax, void* stream);
 int csmae_fp8_quantize(int in_dtype, int fmt, int transpose, long long rows, int cols, const void* src, long long ld, void* dst,
                        long long ldd, const float* amax, float* dq, float* amax_next /* nullable: delayed scaling, += max|src| */, void* stream);
+/* every fp8 weight mirror of a model in three launches (amax, W8, W8^T; blockIdx.y = weight): desc (device, 3 int64 per weight) = {offset of the
+ * fp32 master in p — the same offset is used in the byte mirrors w8 ([out][in]) and w8t ([in][out]) —, out, in}; amax [count][64] zeroed by the
+ * caller, dq [count] receives the de-quantisation factors (current scaling, e4m3). */
+int csmae_fp8_weights(int count, const long long* desc, const float* p, void* w8, void* w8t, float* amax, float* dq, void* stream);
 int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb,
                    void* C, long long ldc, int c_dtype, const float* bias, int epilogue, void* aux, long long ldaux,
                    const void* resid, long long ldr, const float* dq_a, const float* dq_b,

@@ -238,6 +238,31 @@ def test_gemm_fp8_vs_fp32_on_the_quantised_operands(ops, a_fmt):
         assert bool(((deq - want).abs() <= tol).all()), float(((deq - want).abs() - tol).max())
 
 
+def test_fp8_weights_batched_matches_per_weight_quantisation(ops):
+    """csmae_fp8_weights (all weight mirrors of a model in three launches) writes the same bytes and de-quantisation factors as
+    csmae_fp8_amax + csmae_fp8_quantize per weight (plain and transposed mirror)."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(256, 128), (1536, 512), (64, 320), (132, 68)]
+    parts, desc, off = [], [], 0
+    for i, (N, K) in enumerate(shapes):
+        w = torch.randn(N, K, generator=g) * (0.02 * (i + 1))
+        parts.append(w.reshape(-1))
+        desc.append([off, N, K])
+        off += N * K
+    p = dev(torch.cat(parts))
+    w8, w8t = torch.zeros(off, device="cuda", dtype=torch.uint8), torch.zeros(off, device="cuda", dtype=torch.uint8)
+    amax, dq = torch.zeros(len(shapes), ops.FP8_SLOTS, device="cuda"), torch.zeros(len(shapes), device="cuda")
+    ops.fp8_weights(dev(torch.tensor(desc, dtype=torch.long)), p, w8, w8t, amax, dq)
+    for k, ((o, N, K), _) in enumerate(zip(desc, shapes)):
+        w = p[o:o + N * K].view(N, K)
+        a1, d1 = torch.zeros(ops.FP8_SLOTS, device="cuda"), torch.zeros(1, device="cuda")
+        q, qt = torch.empty(N, K, device="cuda", dtype=torch.uint8), torch.empty(K, N, device="cuda", dtype=torch.uint8)
+        ops.fp8_quantize(w, q, a1, d1)
+        ops.fp8_quantize(w, qt, a1, d1, transpose=True)
+        assert torch.equal(w8[o:o + N * K].view(N, K), q) and torch.equal(w8t[o:o + N * K].view(K, N), qt), f"weight {k}"
+        assert float(dq[k]) == float(d1) and float(amax[k].max()) == float(w.abs().max())
+
+
 def test_gemm_rejects_bad_args(ops):
     import csmae_hip
     a = torch.zeros(8, 12, device="cuda", dtype=torch.bfloat16)  # K = 12 not a multiple of 8

@@ -47,8 +47,47 @@ int run(int threads, const char* tag) {
   hipFree(out);
   return 0;
 }
+typedef float f16_t __attribute__((ext_vector_type(16)));
+// bf16 32x32x16 (round 3: the shape with half the MFMA instructions per FLOP), 8 independent accumulators like the others
+__global__ __launch_bounds__(512) void k32(float* out, int iters) {
+  f16_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  bf8_t a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f + i); b[i] = (__bf16)(i * 0.5f); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+int run32(int threads) {
+  float* out; CK(hipMalloc(&out, 1024 * 512 * 4));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 10000, blocks = 256;
+  k32<<<blocks, threads>>>(out, 100);
+  hipEventRecord(e0);
+  k32<<<blocks, threads>>>(out, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  CK(hipGetLastError());
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double flops = 2.0 * 32 * 32 * 16 * 8.0 * iters * (threads / 64) * blocks;
+  printf("%-28s %d waves/CU: %8.3f ms  %8.1f TFLOP/s  (%.1f clk per MFMA per SIMD at 2.4 GHz)\n", "bf16 32x32x16", threads / 64, ms, flops / ms / 1e9,
+         ms * 1e-3 * 2.4e9 / (8.0 * iters * (threads / 64) / 4));
+  hipFree(out);
+  return 0;
+}
 int main() {
   run<0>(256, "bf16 16x16x32"); run<0>(512, "bf16 16x16x32");
+  run32(256); run32(512);
   run<1>(256, "fp8 f8f6f4 16x16x128"); run<1>(512, "fp8 f8f6f4 16x16x128");
   return 0;
 }
