@@ -1208,6 +1208,145 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_kernel(GemmArgs p) {
 #undef EPI_CALL8
 }
 
+// ---- the same product, pipelined (round 3).  The kernel above waits, at every K step, for the DMA it issued one step earlier: two 64-KiB
+// stages leave one step (~2.3 k clocks of MFMA work) to cover an L2 / HBM round trip of 2-4 k clocks under load — it ran at 1.4-1.5 PFLOP/s
+// where the matrix pipe delivers 4.4-4.6 from registers.  Here LDS is the bf16 kernel's ring of five 32-KiB units (one operand's
+// [256 rows][128 B] image each: the byte layout of a bf16 K step of 64), a step consumes units (2j, 2j+1) while 2j+2 .. 2j+4 are in
+// flight or landed, and a step's fragments are read DURING the previous step — fragment i of A right behind the MFMAs of row i, in
+// place; the B fragments behind the last rows, which run column by column so that each B fragment retires early.  One barrier per
+// step, at its head: by then every wave holds the step's fragments in registers, so the two units can be refilled at once.
+template <int AFMT>
+__global__ __launch_bounds__(512, 1) void gemm_fp8_pipe_kernel(GemmArgs p) {
+  constexpr int WM = 128, WN = 64, NWN = 4, NW = 8, FM = 8, FN = 4, UNIT = 256 * 128, NUNIT = 5, PP = UNIT / 1024 / NW;
+  __shared__ __attribute__((aligned(16))) char smem[NUNIT * UNIT];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = lane & 15, g = lane >> 4;
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, tiles);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  GTS(0);
+  const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  // DMA: piece = 8 rows x 128 B; lane -> row (lane >> 3), physical chunk (lane & 7) = logical chunk ^ (row & 7); wave w owns rows 32 w .. 32 w + 31 of an image
+  const int l3 = lane >> 3, kc = ((lane & 7) ^ l3) * 16;
+  const int arow = m0 + w * 32 + l3, brow = n0 + w * 32 + l3;
+  const unsigned avo = (unsigned)((long long)arow * p.lda + kc), bvo = (unsigned)((long long)brow * p.ldb + kc);
+  auto dma_a = [&](int slot, int j, int q) {
+    const bool ok = (arow + q * 8 < p.M) & (j * 128 + kc < p.K);
+    lds_dma16(rsA, ok ? avo + (unsigned)(j * 128) + (unsigned)(q * 8 * p.lda) : OOB_OFF, smem + slot * UNIT + (w * PP + q) * 1024);
+  };
+  auto dma_b = [&](int slot, int j, int q) {
+    const bool ok = (brow + q * 8 < p.N) & (j * 128 + kc < p.K);
+    lds_dma16(rsB, ok ? bvo + (unsigned)(j * 128) + (unsigned)(q * 8 * p.ldb) : OOB_OFF, smem + slot * UNIT + (w * PP + q) * 1024);
+  };
+  f4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const int wm = (w / NWN) * WM, wn = (w % NWN) * WN;
+  const int ra0 = (wm + t) * 128, rb0 = (wn + t) * 128, sw = t & 7;   // (rows wm + 16 i + t share t's swizzle key)
+  const int c0 = ((2 * g) ^ sw) << 4, c1 = ((2 * g + 1) ^ sw) << 4;
+  // Fragment reads are inline assembly into the registers the row's MFMAs have just consumed ("+v": through plain C++ the compiler renames the
+  // re-read values and spills ~90 registers), so their completion is tracked by hand: every read of a step is consumed in the NEXT
+  // step, behind the `lgkmcnt(0)` at its head.  A fragment is two 16-byte halves (chunks 2g and 2g + 1 of the lane's row).
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+  u4_t alo[FM], ahi[FM], blo[FN], bhi[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) { alo[i] = u4_t{0, 0, 0, 0}; ahi[i] = u4_t{0, 0, 0, 0}; }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) { blo[j] = u4_t{0, 0, 0, 0}; bhi[j] = u4_t{0, 0, 0, 0}; }
+  auto read_frag = [&](int slot, int r0, auto ic, u4_t& lo, u4_t& hi) {   // fragment `ic` (16 rows = 2048 B apart) of the image in `slot`, rows from r0
+    constexpr int i = decltype(ic)::value;
+    const unsigned a0 = lds0 + (unsigned)(slot * UNIT + r0 + c0), a1 = lds0 + (unsigned)(slot * UNIT + r0 + c1);
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(lo) : "v"(a0), "n"(i * 2048));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(hi) : "v"(a1), "n"(i * 2048));
+  };
+  auto read_a = [&](int slot, auto ic) { read_frag(slot, ra0, ic, alo[decltype(ic)::value], ahi[decltype(ic)::value]); };
+  auto read_b = [&](int slot, auto jc) { read_frag(slot, rb0, jc, blo[decltype(jc)::value], bhi[decltype(jc)::value]); };
+  auto join8 = [](u4_t lo, u4_t hi) { return i8v_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}; };
+  const int nsteps = p.ktiles, U = 2 * nsteps;
+  const int issued0 = min(NUNIT - 1, U - 1);
+#pragma unroll
+  for (int u = 0; u < NUNIT; ++u)
+    if (u <= issued0) {
+#pragma unroll
+      for (int q = 0; q < PP; ++q) { if (u & 1) dma_b(u, u >> 1, q); else dma_a(u, u >> 1, q); }
+    }
+  if (issued0 >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PP) : "memory");   // units 2, 3, 4 may stay in flight
+  else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  GTS(1);
+  static_for<FN>([&](auto jc) { read_b(1, jc); });
+  static_for<FM>([&](auto ic) { read_a(0, ic); });
+  auto nxt = [](int s, int k) { s += k; return s >= NUNIT ? s - NUNIT : s; };
+#define FP8_MMA(i, j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(join8(blo[j], bhi[j]), join8(alo[i], ahi[i]), acc[i][j], 0, AFMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f)
+  // A step is straight-line code (run-time conditions around the reads and DMA pieces made the compiler copy fragment and accumulator
+  // tuples between basic blocks and spill ~90 registers), so — as in the bf16 kernel — the last three steps, which fetch less or nothing
+  // and read no next fragments, are instantiations of their own: MODE 0 fetches units 2j+5 and 2j+6, 1 only 2j+5, 2 nothing, 3 = last step.
+  auto step = [&](int j, int sl, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool more = MODE < 3;
+    // this wave's pieces of the NEXT step's units (2 j + 2, 2 j + 3) have landed; unit 2 j + 4 (issued during the previous step) may stay in flight
+    // (the first step too: the prologue only waited for units 0 and 1, this step reads the next step's fragments out of units 2 and 3)
+    if (MODE <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's fragments have arrived (and, with the barrier, everybody's reads of its two units are done)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int sb_cur = nxt(sl, 1), sa = nxt(sl, 2), sb = nxt(sl, 3);
+    static_for<FM - 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+#pragma unroll
+      for (int jj = 0; jj < FN; ++jj) FP8_MMA(i, jj);
+      if (more) read_a(sa, ic);
+      // the 2 x PP pieces of the two freed units over the first PP rows: unit 2 j + 5 (B of step j + 2) into this step's A slot, 2 j + 6 into its B slot
+      if (i < PP) { if (MODE <= 1) dma_b(sl, j + 2, i); if (MODE == 0) dma_a(sb_cur, j + 3, i); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<FN>([&](auto jc) {   // the last two rows column by column: B fragment jj retires here and is re-read for the next step
+      constexpr int jj = decltype(jc)::value;
+      FP8_MMA(FM - 2, jj); FP8_MMA(FM - 1, jj);
+      if (more) read_b(sb, jc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (more) { read_a(sa, std::integral_constant<int, FM - 2>{}); read_a(sa, std::integral_constant<int, FM - 1>{}); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int j = 0, sl = 0;   // sl: slot of the current step's A unit (unit 2 j); its B unit sits in nxt(sl, 1), the next step's in nxt(sl, 2) / nxt(sl, 3)
+  for (; j < nsteps - 3; ++j, sl = nxt(sl, 2)) step(j, sl, std::integral_constant<int, 0>{});
+  if (nsteps >= 3) { step(j, sl, std::integral_constant<int, 1>{}); ++j; sl = nxt(sl, 2); }
+  if (nsteps >= 2) { step(j, sl, std::integral_constant<int, 2>{}); ++j; sl = nxt(sl, 2); }
+  step(j, sl, std::integral_constant<int, 3>{});
+  GTS(2);
+#undef FP8_MMA
+  const float alpha = (p.dq_a ? p.dq_a[0] : 1.f) * (p.dq_b ? p.dq_b[0] : 1.f);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] *= alpha;
+  // (no barrier: the last step reads nothing from the ring after its head barrier, and every DMA has landed)
+  constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
+  void* Cptr = p.C;
+  float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
+#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+#define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
+  const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
+                                                                                   : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));
+  if (p.c_dtype == CSMAE_BF16) {
+    if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
+    else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
+    else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
+    else EPI_CALL(bf16_t, EPI_NONE);
+  } else {
+    if (p.epi == EPI_GELU) EPI_CALL(float, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(float, EPI_DGELU);
+    else if (p.epi == EPI_RESID) EPI_CALL(float, EPI_RESID); else EPI_CALL(float, EPI_NONE);
+  }
+#undef EPI_CALL
+#undef EPI_CALL8
+  GTS(3);
+}
+
 extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb,
                               void* C, long long ldc, int c_dtype, const float* bias, int epilogue, void* aux, long long ldaux,
                               const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* q_out, long long ldq, int q_fmt,
@@ -1238,8 +1377,12 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
                   "csmae_gemm_fp8: the fused fp8 copy needs a bf16 output with 8-element aligned rows and the three scale pointers");
   }
   dim3 grid(p.tiles_m * p.tiles_n);
-  if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gemm_fp8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
+  static const bool two_stage = getenv("CSMAE_FP8_TWO_STAGE") != nullptr;   // A/B aid: the first (two-stage, barrier-per-step) kernel
+  if (two_stage) {
+    if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_fp8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
+  } else if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_pipe_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_fp8_pipe_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
   return csmae_check_launch("csmae_gemm_fp8");
 }
 
