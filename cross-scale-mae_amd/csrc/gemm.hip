@@ -54,8 +54,10 @@ struct GemmArgs {
   //    wrote, st_out[tn * st_stride + 2 m] — the statistics pass of LayerNorm without a second read of x;
   //  consumer side: A = x itself, B = W diag(gamma) (bf16), C = rstd[m] (acc - mean[m] ln_c[n]) + bias[n] with ln_c[n] = sum_k B[n,k] and
   //    bias = b + W beta, the row statistics folded from the st_parts partials; the tn == 0 tiles leave mean / rstd for the backward pass.
-  float* st_out; const float* st_in; long long st_stride; int st_parts; const float* ln_c; float ln_eps; float* ln_mean; float* ln_rstd;
+  // (these travel in a kernel argument of their own, LnArgs, and only to the two instantiations that use them: eight more kernel-argument
+  // words in GemmArgs cost every GEMM launch of the step ~1 %)
 };
+struct LnArgs { float* st_out; const float* st_in; long long st_stride; int st_parts; const float* ln_c; float ln_eps; float* ln_mean; float* ln_rstd; };
 
 // gelu'(x) lies in [-0.129, 1.129]: stored as the 8-bit code q = round(200 g + 26) (range [-0.13, 1.145], step 5e-3, |error| <= 2.5e-3 — the
 // size of a bf16 rounding step at 1) it costs one byte instead of two in the two epilogues that are bound by their HBM bytes (fc1 writes h
@@ -237,19 +239,19 @@ __device__ __forceinline__ float sum8(float v) {
 #define LN_MAXP 5   // column tiles of the producer: ceil(D / 256) for D <= 1280
 struct LnStatRegs { f2_t v[2][LN_MAXP]; };
 template <int WM>
-__device__ __forceinline__ void ln_stats_issue(const GemmArgs& p, LnStatRegs& sr, int lane, int mbase) {
+__device__ __forceinline__ void ln_stats_issue(const GemmArgs& p, const LnArgs& ln, LnStatRegs& sr, int lane, int mbase) {
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const int gm = min(mbase + min(rr * 64 + lane, WM - 1), p.M - 1);
 #pragma unroll
     for (int pp = 0; pp < LN_MAXP; ++pp) {   // (parts beyond st_parts re-read the last one and are not summed: no branch, no dynamic register index)
-      const float* ptr = p.st_in + (long long)min(pp, p.st_parts - 1) * p.st_stride + 2ll * gm;
+      const float* ptr = ln.st_in + (long long)min(pp, ln.st_parts - 1) * ln.st_stride + 2ll * gm;
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sr.v[rr][pp]) : "v"(ptr) : "memory");
     }
   }
 }
 template <int WM>   // call behind a wait that covers the loads of ln_stats_issue; returns (rstd, -mean rstd) of rows lane and 64 + lane of the wave's tile
-__device__ __forceinline__ void ln_stats_fold(const GemmArgs& p, LnStatRegs& sr, float2 (&st)[2], int lane, int mbase, bool writer) {
+__device__ __forceinline__ void ln_stats_fold(const GemmArgs& p, const LnArgs& ln, LnStatRegs& sr, float2 (&st)[2], int lane, int mbase, bool writer) {
   const float invK = 1.0f / (float)p.K;
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
@@ -257,22 +259,22 @@ __device__ __forceinline__ void ln_stats_fold(const GemmArgs& p, LnStatRegs& sr,
 #pragma unroll
     for (int pp = 0; pp < LN_MAXP; ++pp) {
       asm volatile("" : "+v"(sr.v[rr][pp]));   // (ordered behind the wait: the compiler knows nothing about the asm loads' latency)
-      if (pp < p.st_parts) { s += sr.v[rr][pp][0]; q += sr.v[rr][pp][1]; }
+      if (pp < ln.st_parts) { s += sr.v[rr][pp][0]; q += sr.v[rr][pp][1]; }
     }
-    const float mean = s * invK, var = fmaxf(q * invK - mean * mean, 0.f), rstd = rsqrtf(var + p.ln_eps);
+    const float mean = s * invK, var = fmaxf(q * invK - mean * mean, 0.f), rstd = rsqrtf(var + ln.ln_eps);
     st[rr] = make_float2(rstd, -mean * rstd);
     const int r = rr * 64 + lane;
-    if (writer && r < WM && mbase + r < p.M) { p.ln_mean[mbase + r] = mean; p.ln_rstd[mbase + r] = rstd; }
+    if (writer && r < WM && mbase + r < p.M) { ln.ln_mean[mbase + r] = mean; ln.ln_rstd[mbase + r] = rstd; }
   }
 }
 template <int FN, int FM> struct LnFoldRegs { f4_t c4[FN], b4[FN]; float2 st[FM]; };
 template <int FN, int FM, int WM>
-__device__ __forceinline__ void ln_fold_prepare(const GemmArgs& p, LnFoldRegs<FN, FM>& lf, const float2 (&st)[2], float* sw, int lane, int t, int g, int nbase) {
+__device__ __forceinline__ void ln_fold_prepare(const GemmArgs& p, const LnArgs& ln, LnFoldRegs<FN, FM>& lf, const float2 (&st)[2], float* sw, int lane, int t, int g, int nbase) {
 #pragma unroll
   for (int j = 0; j < FN; ++j) {   // (issued first: their latency runs under the LDS round trip below)
     const int n = nbase + j * 16 + 4 * g;
     const bool ok = n < p.N;
-    lf.c4[j] = ok ? *reinterpret_cast<const f4_t*>(p.ln_c + n) : f4_t{0.f, 0.f, 0.f, 0.f};
+    lf.c4[j] = ok ? *reinterpret_cast<const f4_t*>(ln.ln_c + n) : f4_t{0.f, 0.f, 0.f, 0.f};
     lf.b4[j] = (ok && p.bias) ? *reinterpret_cast<const f4_t*>(p.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
   }
   // lane L holds the statistics of rows L and 64 + L; fragment row i wants row 16 i + (lane & 15): one trip through a wave-private LDS
@@ -710,8 +712,9 @@ extern "C" int csmae_debug_gemm_ts(unsigned long long* out) { return (int)hipMem
 // dense 256 x 256 slabs) and its column-sum partials ([nsplit][nslots][256]) when a tile is cut into several slices.
 struct DwFold { float* slab; float* cs_slab; int nsplit; int slot; int nslots; };
 
-template <bool TA, bool TB, int BM, bool GROUP, bool LNF = false>   // LNF: consumer side of the LayerNorm fold (its own instantiation: a run-time branch around 128 accumulator updates made the allocator spill)
-__device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold fold) {
+template <bool TA, bool TB, int BM, bool GROUP, int LNM = 0>   // LNF: consumer side of the LayerNorm fold (its own instantiation: a run-time branch around 128 accumulator updates made the allocator spill)
+__device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold fold, const LnArgs& ln = LnArgs{}) {
+  constexpr bool LNF = LNM == 1, LNS = LNM == 2;   // LayerNorm fold: consumer side / producer side (row statistics of the stream it writes)
   static_assert(BM == 256 || (BM == 192 && !TA), "192-row tiles exist for K-contiguous A only");
   constexpr int BN = 256, WM = BM / 2, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
   constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;  // ring slot = 32 KiB; a B image fills it, a 192-row A image uses 24 KiB
@@ -726,7 +729,7 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   GTS(0);
   LnStatRegs lnsr;
   float2 lnst[2];
-  if (LNF) ln_stats_issue<BM / 2>(p, lnsr, lane, m0 + (w / 4) * (BM / 2));
+  if (LNF) ln_stats_issue<BM / 2>(p, ln, lnsr, lane, m0 + (w / 4) * (BM / 2));
   const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   const unsigned kstepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
   const unsigned kstepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
@@ -879,7 +882,7 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPA + PPU) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (LNF) ln_stats_fold<BM / 2>(p, lnsr, lnst, lane, m0 + (w / 4) * (BM / 2), tn == 0 && (w % 4) == 0);   // (the loads are older than the prologue's DMA pieces: the wait above covers them)
+  if (LNF) ln_stats_fold<BM / 2>(p, ln, lnsr, lnst, lane, m0 + (w / 4) * (BM / 2), tn == 0 && (w % 4) == 0);   // (the loads are older than the prologue's DMA pieces: the wait above covers them)
   GTS(1);
   s8_t fa[FM], fb0[FN], fb1[FN];
   if (USE_ASM) {  // (asm reads carry their destination as "+v": give the registers a defined value once)
@@ -996,7 +999,7 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   float* lnp = reinterpret_cast<float*>(smem + STRIP);
   if (LNF) {   // consumer side of the LayerNorm fold (csmae_gemm_lnfold: bf16 C, 16-byte rows, plain or GELU epilogue — checked on the host)
     LnFoldRegs<FN, FM> lf;
-    ln_fold_prepare<FN, FM, WM>(p, lf, lnst, lnp + w * (WM * 2), lane, t, g, n0 + wn);
+    ln_fold_prepare<FN, FM, WM>(p, ln, lf, lnst, lnp + w * (WM * 2), lane, t, g, n0 + wn);
     GemmArgs pe = p;
     pe.bias = nullptr;   // (the bias enters with the fold)
     if (p.epi == EPI_GELU) epilogue_rows_bf16x8<EPI_GELU, FM, FN, WM, EROWS, ESTR, true>(pe, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g, nullptr, &lf);
@@ -1004,7 +1007,7 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
     GTS(3);
     return;
   }
-  float* srow = (!TA && !TB && p.st_out != nullptr) ? lnp + ((w % NWN) * BM + wm) * 2 : nullptr;
+  float* srow = LNS ? lnp + ((w % NWN) * BM + wm) * 2 : nullptr;
 #define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
 #define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g, srow)
   const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
@@ -1022,19 +1025,19 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   }
 #undef EPI_CALL
 #undef EPI_CALL8
-  if (!TA && !TB && p.st_out != nullptr) {   // (workgroup-uniform) fold the four column waves' row statistics: one (sum, sumsq) per row of this tile
+  if (LNS) {   // fold the four column waves' row statistics: one (sum, sumsq) per row of this tile
     __syncthreads();
     if (threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int k = 0; k < NWN; ++k) { const float2 v = *reinterpret_cast<const float2*>(lnp + (k * BM + threadIdx.x) * 2); s += v.x; q += v.y; }
-      *reinterpret_cast<float2*>(p.st_out + (long long)tn * p.st_stride + 2ll * (m0 + threadIdx.x)) = make_float2(s, q);
+      *reinterpret_cast<float2*>(ln.st_out + (long long)tn * ln.st_stride + 2ll * (m0 + threadIdx.x)) = make_float2(s, q);
     }
   }
   GTS(3);
 }
 
-template <bool TA, bool TB, int BM = 256, bool LNF = false>  // BM = 192 (K-contiguous A only): 6 instead of 8 A fragments per wave, for outputs whose 256-row
+template <bool TA, bool TB, int BM = 256>  // BM = 192 (K-contiguous A only): 6 instead of 8 A fragments per wave, for outputs whose 256-row
 __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  // tiling leaves too many CUs idle (N = 768: 150 -> 201 tiles)
   const int tiles = p.tiles_m * p.tiles_n;
   const int wg = xcd_remap(blockIdx.x, tiles * p.splitk);
@@ -1043,7 +1046,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   const int kt_begin = split * p.ktiles_per_split;
   const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles);
   if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
-  k64_tile<TA, TB, BM, false, LNF>(p, tm, tn, split, kt_begin, kt_end, DwFold{});
+  k64_tile<TA, TB, BM, false>(p, tm, tn, split, kt_begin, kt_end, DwFold{});
+}
+template <int BM, int LNM>   // the two sides of the LayerNorm fold (x W^T products only): LNM 1 = consumer (csmae_gemm_lnfold), 2 = producer (csmae_gemm_resid_stats)
+__global__ __launch_bounds__(512, 1) void gemm_bf16_k64_ln_kernel(GemmArgs p, LnArgs ln) {
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  k64_tile<false, false, BM, false, LNM>(p, tm, tn, 0, 0, p.ktiles, DwFold{}, ln);
 }
 
 // ---- grouped weight gradients: the dW products of a transformer block (qkv, proj, fc1, fc2 — same token axis K) in ONE launch.
@@ -1075,7 +1084,6 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
   p.c_dtype = CSMAE_F32; p.epi = EPI_RESID; p.splitk = ga.nsplit; p.tiles_m = 0; p.tiles_n = d.tiles_n; p.ktiles = ga.ktiles; p.ktiles_per_split = ga.ktiles_per_split;
   p.a_bytes = (unsigned)((long long)ga.K * d.ldy * 2); p.b_bytes = (unsigned)((long long)ga.K * d.ldx * 2);
   p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = 0; p.q_out = nullptr;
-  p.st_out = nullptr; p.st_in = nullptr;
   k64_tile<true, true, 256, true>(p, tm, tn, split, kt_begin, kt_end, DwFold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles});
 }
 // fold of the K slices of a grouped launch: workgroup (tile, part) adds the tile's slabs in slice order and accumulates 16 rows into
@@ -1362,7 +1370,7 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
   CSMAE_REQUIRE(epilogue != EPI_RESID || (resid && ldr % 4 == 0), "csmae_gemm_fp8: residual epilogue needs resid");
   CSMAE_REQUIRE(M * lda < 0xFFFFFFF0ll && N * ldb < 0xFFFFFFF0ll, "csmae_gemm_fp8: operand larger than 4 GiB");
   GemmArgs p;
-  p.force_cfg = 0; p.split_stride = 0; p.colsum = nullptr; p.st_out = nullptr; p.st_in = nullptr;
+  p.force_cfg = 0; p.split_stride = 0; p.colsum = nullptr;
   p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = 1;
@@ -1463,20 +1471,21 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
   p.split_stride = M * ldc;
   p.colsum = (epilogue == EPI_SPLIT && transA && transB && dtype == CSMAE_BF16) ? reinterpret_cast<float*>(aux) : nullptr;
   p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = q8; p.q_out = nullptr;
-  p.st_out = nullptr; p.st_in = nullptr; p.st_stride = 0; p.st_parts = 0; p.ln_c = nullptr; p.ln_eps = 0.f; p.ln_mean = p.ln_rstd = nullptr;
+  LnArgs la{nullptr, nullptr, 0, 0, nullptr, 0.f, nullptr, nullptr};
   if (ln) {   // LayerNorm fold: both sides live in the pipelined kernel's 16-byte-row bf16 epilogues
     CSMAE_REQUIRE(dtype == CSMAE_BF16 && c_dtype == CSMAE_BF16 && !transA && !transB && splitk == 1 && g_force_cfg < 0 && ldc % 8 == 0 && N % 8 == 0,
                   "csmae_gemm (LayerNorm fold): bf16 x W^T products with 8-element aligned rows only");
+    CSMAE_REQUIRE((ln->st_out != nullptr) != (ln->st_in != nullptr), "csmae_gemm (LayerNorm fold): a launch is either the producer or the consumer side");
     if (ln->st_out) {
       CSMAE_REQUIRE(epilogue == EPI_RESID && ldr % 8 == 0 && ((uintptr_t)resid & 15) == 0 && ln->st_stride >= 2 * M && ((uintptr_t)ln->st_out & 7) == 0,
                     "csmae_gemm_resid_stats: residual epilogue with 16-byte aligned rows, st_stride >= 2 M");
-      p.st_out = ln->st_out; p.st_stride = ln->st_stride;
+      la.st_out = ln->st_out; la.st_stride = ln->st_stride;
     }
     if (ln->st_in) {
-      CSMAE_REQUIRE((epilogue == EPI_NONE || (epilogue == EPI_GELU && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0)) && ln->st_parts >= 1 && ln->ln_c && ln->mean && ln->rstd &&
+      CSMAE_REQUIRE((epilogue == EPI_NONE || (epilogue == EPI_GELU && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0)) && ln->st_parts >= 1 && ln->st_parts <= LN_MAXP && ln->ln_c && ln->mean && ln->rstd &&
                     ln->st_stride >= 2 * M && ((uintptr_t)ln->st_in & 7) == 0 && ((uintptr_t)ln->ln_c & 15) == 0,
-                    "csmae_gemm_lnfold: plain or GELU epilogue, the partial statistics, c, mean and rstd are required");
-      p.st_in = ln->st_in; p.st_stride = ln->st_stride; p.st_parts = ln->st_parts; p.ln_c = ln->ln_c; p.ln_eps = ln->eps; p.ln_mean = ln->mean; p.ln_rstd = ln->rstd;
+                    "csmae_gemm_lnfold: plain or GELU epilogue, the partial statistics (at most 5 parts), c, mean and rstd are required");
+      la.st_in = ln->st_in; la.st_stride = ln->st_stride; la.st_parts = ln->st_parts; la.ln_c = ln->ln_c; la.ln_eps = ln->eps; la.ln_mean = ln->mean; la.ln_rstd = ln->rstd;
     }
   }
   p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
@@ -1523,10 +1532,12 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
     else if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, false>), grid, dim3(512), 0, st, p);  \
     else if (cfg == 3) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, true>), grid, dim3(512), 0, st, p);   \
     else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4, false>), grid, dim3(256), 0, st, p);
-    if (p.st_in != nullptr) {
-      CSMAE_REQUIRE(cfg == 4 || cfg == 5, "csmae_gemm_lnfold: needs the pipelined kernel");
-      if (cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false, 192, true>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false, 256, true>), grid, dim3(512), 0, st, p);
+    if (ln) {
+      CSMAE_REQUIRE(cfg == 4 || cfg == 5, "csmae_gemm (LayerNorm fold): needs the pipelined kernel");
+      if (la.st_in && cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<192, 1>), grid, dim3(512), 0, st, p, la);
+      else if (la.st_in) hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<256, 1>), grid, dim3(512), 0, st, p, la);
+      else if (cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<192, 2>), grid, dim3(512), 0, st, p, la);
+      else hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<256, 2>), grid, dim3(512), 0, st, p, la);
     }
     else if (cfg == 5 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false, 192>), grid, dim3(512), 0, st, p);
     else if (cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, true, 192>), grid, dim3(512), 0, st, p);

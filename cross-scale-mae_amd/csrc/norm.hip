@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const T
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ;  dres_out = dres_in + dx ;  dgamma += dy*xhat ; dbeta += dy
 // TX = type of the residual stream: x, and the residual-gradient stream dres_in / dx_out (fp32, or bf16 in throughput mode, where
 // dx_out itself is the next GEMM's operand and dx_lp is null)
-template <typename TDY, typename TX, typename TLP, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(long long M, int D, const TDY* __restrict__ dy, const TX* __restrict__ x,
+template <typename TDY, typename TX, typename TLP, int NV>   // (occupancy steps: NV = 3, D = 768, held to 128 registers = four waves per SIMD — at 130, three, every encoder launch ran 20 % longer —; NV = 2, D = 512, to 96 = five)
+__global__ __launch_bounds__(256, NV == 3 ? 4 : (NV == 2 ? 5 : 1)) void ln_bwd_kernel(long long M, int D, const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const TX* __restrict__ dres_in,
                                                      TX* __restrict__ dx_out, TLP* __restrict__ dx_lp,
