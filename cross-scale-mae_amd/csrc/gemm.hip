@@ -359,7 +359,10 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
       const float* src = ew + (ps * RPP + rsub) * ESTR + col;
       f4_t v0 = *reinterpret_cast<const f4_t*>(src) + b0, v1 = *reinterpret_cast<const f4_t*>(src + 4) + b1;
       f4_t o0 = v0, o1 = v1;
-      if (EPI == EPI_GELU) { const f4_t x0 = v0, x1 = v1; gelu_both4<bf16_t>(x0, o0, v0); gelu_both4<bf16_t>(x1, o1, v1); }
+#ifndef GEMM_EPI_ABL
+#define GEMM_EPI_ABL 0   // epilogue ablations, compile-time only (tools/gemm_variants.sh): 1 no GELU arithmetic | 2 no gelu' store | 4 no C store
+#endif
+      if (EPI == EPI_GELU && !(GEMM_EPI_ABL & 1)) { const f4_t x0 = v0, x1 = v1; gelu_both4<bf16_t>(x0, o0, v0); gelu_both4<bf16_t>(x1, o1, v1); }
       if (EPI == EPI_DGELU || EPI == EPI_RESID) {
         const uint4 a = ld[part & 1][ps];
         f4_t a0 = f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
@@ -395,7 +398,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
         if (ok1) *reinterpret_cast<uint2*>(qd) = make_uint2((unsigned)w0, (unsigned)w1);
         else *reinterpret_cast<unsigned*>(qd) = (unsigned)w0;
       }
-      if (EPI == EPI_GELU && p.aux_q8) {
+      if (EPI == EPI_GELU && p.aux_q8 && !(GEMM_EPI_ABL & 2)) {
         // 8-bit gelu': a lane's 8 columns are 8 bytes, and this epilogue is bound by the NUMBER of store instructions its CU issues.
         // Neighbouring lanes (columns 16k.. and 16k+8.. of one row) trade the codes of two consecutive passes, so that the even
         // lane stores 16 bytes of the first pass's row and the odd lane 16 bytes of the second's: one gelu' store per two passes.
@@ -419,7 +422,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
           else if (gm < p.M) *reinterpret_cast<uint4*>(a8 + (long long)gm * p.ldaux + gn - 8) = make_uint4(recv.x, recv.y, mine.x, mine.y);
         }
       }
-      if (gm < p.M) {
+      if (gm < p.M && !(GEMM_EPI_ABL & 4)) {
         if (ok1) {
           if (EPI == EPI_GELU && !p.aux_q8) *reinterpret_cast<uint4*>(X + (long long)gm * p.ldaux + gn) = make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
           *reinterpret_cast<uint4*>(C + (long long)gm * p.ldc + gn) = make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
