@@ -418,8 +418,11 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
           uint2 recv;
           recv.x = (unsigned)__shfl_xor((int)send.x, 1); recv.y = (unsigned)__shfl_xor((int)send.y, 1);
           if (!pair_ok) { st8(gm - RPP, gp_prev); st8(gm, mine); }
-          else if (!odd) { if (gm - RPP < p.M) *reinterpret_cast<uint4*>(a8 + (long long)(gm - RPP) * p.ldaux + gn) = make_uint4(gp_prev.x, gp_prev.y, recv.x, recv.y); }
-          else if (gm < p.M) *reinterpret_cast<uint4*>(a8 + (long long)gm * p.ldaux + gn - 8) = make_uint4(recv.x, recv.y, mine.x, mine.y);
+          else {   // ONE store instruction for the lane pair's two rows (an even-lane store and an odd-lane store, each half empty, cost what two 8-byte stores cost)
+            const int row = odd ? gm : gm - RPP;
+            const uint4 val = odd ? make_uint4(recv.x, recv.y, mine.x, mine.y) : make_uint4(gp_prev.x, gp_prev.y, recv.x, recv.y);
+            if (row < p.M) *reinterpret_cast<uint4*>(a8 + (long long)row * p.ldaux + (odd ? gn - 8 : gn)) = val;
+          }
         }
       }
       if (gm < p.M && !(GEMM_EPI_ABL & 4)) {
