@@ -442,6 +442,113 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   }
 }
 
+// The same epilogue with buffer addressing (round 3).  The epilogues are bound by their VALU instruction count (tools/epi_abl.py: the
+// fc1 epilogue's ~18 k clocks are its ~18 operations per element x 128 elements per lane x two waves per SIMD x 4 clocks), and a good part
+// of what is not arithmetic was addressing: a 64-bit multiply-add chain per load / store and per pass, a row-bound compare with an
+// exec-mask dance around every store.  Here every tensor is a buffer resource whose size ends at row M: a lane's byte offset advances by ONE
+// 32-bit add per pass, rows beyond M are dropped by the hardware's range check, columns beyond N are marked out of range once per tile.
+// Requirements (checked by the caller): N % 8 == 0 (a lane's 8 columns are valid or not as a whole), (M + 256) rows of every tensor < 4 GiB,
+// no fused fp8 copy.  Same arithmetic, same bytes as epilogue_rows_bf16x8.
+typedef __amdgpu_buffer_rsrc_t brsrc_t;
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ brsrc_t buf_rsrc(const void* ptr, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)(unsigned)bytes, 0x00020000);
+}
+template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR, bool LNF = false>
+__device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g,
+                                                      float* srow = nullptr, const LnFoldRegs<FN, FM>* lf = nullptr) {
+  constexpr int LPR = FN * 16 / 8, RPP = 64 / LPR, NPASS = EROWS / RPP, NPART = WM / EROWS;
+  constexpr bool NEEDS_LOAD = EPI == EPI_DGELU || EPI == EPI_RESID;
+  const int col = (lane % LPR) * 8, rsub = lane / LPR;
+  const int gn = nbase + col;
+  const bool colok = gn < p.N;
+  f4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (p.bias && colok) { b0 = *reinterpret_cast<const f4_t*>(p.bias + gn); b1 = *reinterpret_cast<const f4_t*>(p.bias + gn + 4); }
+  const int row0 = mbase + rsub;
+  // byte offsets of the lane's 8 columns in row `row0` of C / the tensor a part loads (residual stream or gelu') / the 8-bit gelu' codes; one add per pass
+  const brsrc_t rsC = buf_rsrc(p.C, (long long)p.M * p.ldc * 2);
+  unsigned offC = colok ? (unsigned)(((long long)row0 * p.ldc + gn) * 2) : OOB_OFF;
+  const unsigned stepC = colok ? (unsigned)(RPP * p.ldc * 2) : 0u;   // (a lane beyond N stays out of range: its offset must not wrap back into the tensor)
+  const bool q8 = p.aux_q8 != 0;
+  const long long lds_ = EPI == EPI_RESID ? p.ldr : p.ldaux;
+  const int esz = (EPI != EPI_RESID && q8) ? 1 : 2;                         // bytes per element of the loaded / aux tensor
+  const void* lptr = EPI == EPI_RESID ? p.resid : p.aux;
+  const brsrc_t rsL = buf_rsrc((EPI == EPI_NONE) ? p.C : lptr, (EPI == EPI_NONE) ? 0 : (long long)p.M * lds_ * esz);
+  unsigned offL = colok ? (unsigned)(((long long)row0 * lds_ + gn) * esz) : OOB_OFF;
+  const unsigned stepL = colok ? (unsigned)(RPP * lds_ * esz) : 0u;
+  // (8-bit gelu' stores in 16-byte pieces, see the store loop: rows of aux 16-byte aligned, passes in pairs, all 16 columns of a lane pair inside N)
+  const bool gp16 = EPI == EPI_GELU && q8 && (NPASS % 2 == 0) && p.ldaux % 16 == 0 && ((uintptr_t)p.aux & 15) == 0;
+  const bool pair_ok = nbase + ((lane % LPR) & ~1) * 8 + 16 <= p.N;
+  const bool odd = lane & 1;
+  uint2 gp_prev = make_uint2(0u, 0u);
+  unsigned offL_prev = offL;
+  uint4 ld[2][NPASS];   // (dead code unless NEEDS_LOAD)
+  auto load_part = [&](uint4 (&dst)[NPASS]) {   // the loads of the NEXT part: offL runs ahead of the stores by one part
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      if (EPI == EPI_DGELU && q8) { const uint2 h = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsL, offL, 0, 0)); dst[ps] = make_uint4(h.x, h.y, 0u, 0u); }
+      else dst[ps] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsL, offL, 0, 0));
+      offL += stepL;
+    }
+  };
+  if (NEEDS_LOAD) load_part(ld[0]);
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) {
+#pragma unroll
+    for (int ii = 0; ii < EROWS / 16; ++ii)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        f4_t v = acc[part * (EROWS / 16) + ii][j];
+        if (LNF) v = ln_fold_frag<FN, FM>(*lf, v, part * (EROWS / 16) + ii, j);
+        *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = v;
+      }
+    if (NEEDS_LOAD && part + 1 < NPART) load_part(ld[(part + 1) & 1]);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const float* src = ew + (ps * RPP + rsub) * ESTR + col;
+      f4_t v0 = *reinterpret_cast<const f4_t*>(src) + b0, v1 = *reinterpret_cast<const f4_t*>(src + 4) + b1;
+      f4_t o0 = v0, o1 = v1;
+      if (EPI == EPI_GELU && !(GEMM_EPI_ABL & 1)) { const f4_t x0 = v0, x1 = v1; gelu_both4<bf16_t>(x0, o0, v0); gelu_both4<bf16_t>(x1, o1, v1); }
+      if (EPI == EPI_DGELU || EPI == EPI_RESID) {
+        const uint4 a = ld[part & 1][ps];
+        f4_t a0 = f4_t{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+        f4_t a1 = f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
+        if (EPI == EPI_DGELU && q8) { a0 = gp_q8_unpack4(a.x); a1 = gp_q8_unpack4(a.y); }
+        if (EPI == EPI_DGELU) { o0 = v0 * a0; o1 = v1 * a1; } else { o0 = v0 + a0; o1 = v1 + a1; }
+      }
+      if (EPI == EPI_RESID && srow != nullptr) {   // row statistics of the stream this epilogue writes, of the ROUNDED values (see epilogue_rows_bf16x8)
+        const f4_t r0 = round4<bf16_t>(o0), r1 = round4<bf16_t>(o1);
+        const float s = sum8(((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3])));
+        const float q = sum8(fmaf(r0[0], r0[0], fmaf(r0[1], r0[1], fmaf(r0[2], r0[2], r0[3] * r0[3]))) + fmaf(r1[0], r1[0], fmaf(r1[1], r1[1], fmaf(r1[2], r1[2], r1[3] * r1[3]))));
+        if ((lane % LPR) == 0) *reinterpret_cast<float2*>(srow + 2 * (part * EROWS + ps * RPP + rsub)) = make_float2(s, q);
+      }
+      if (EPI == EPI_GELU && !(GEMM_EPI_ABL & 2)) {
+        if (!q8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]))), rsL, offL, 0, 0);
+        else {
+          // a lane's 8 codes are 8 bytes; neighbouring lanes trade the codes of two consecutive passes so that each stores 16 bytes of ONE row
+          const uint2 mine = make_uint2(gp_q8_pack4(v0), gp_q8_pack4(v1));
+          if (!gp16) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, mine), rsL, offL, 0, 0);
+          else if ((ps & 1) == 0) { gp_prev = mine; offL_prev = offL; }
+          else {
+            const uint2 send = odd ? gp_prev : mine;
+            uint2 recv;
+            recv.x = (unsigned)__shfl_xor((int)send.x, 1); recv.y = (unsigned)__shfl_xor((int)send.y, 1);
+            if (!pair_ok) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, gp_prev), rsL, offL_prev, 0, 0); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, mine), rsL, offL, 0, 0); }
+            else {
+              const uint4 val = odd ? make_uint4(recv.x, recv.y, mine.x, mine.y) : make_uint4(gp_prev.x, gp_prev.y, recv.x, recv.y);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, val), rsL, odd ? offL - 8u : offL_prev, 0, 0);
+            }
+          }
+        }
+        offL += stepL;
+      }
+      if (!(GEMM_EPI_ABL & 4))
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]))), rsC, offC, 0, 0);
+      offC += stepC;
+    }
+  }
+}
+
 // bf16 output with nothing but the bias to add (qkv forward, the dX products of fc1 / qkv / proj): the tile crosses the strip as bf16,
 // not as fp32.  A 256 x 256 tile's epilogue (7 k clocks at K = 512 .. 768, a quarter of the tile) spent 3.3 k of them pushing 256 KiB
 // of fp32 accumulators through ds_write_b128 (13 clocks per KiB); rounding first halves the bytes written and read and leaves the
@@ -1008,7 +1115,8 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
     ln_fold_prepare<FN, FM, WM>(p, ln, lf, lnst, lnp + w * (WM * 2), lane, t, g, n0 + wn);
     GemmArgs pe = p;
     pe.bias = nullptr;   // (the bias enters with the fold)
-    if (p.epi == EPI_GELU) epilogue_rows_bf16x8<EPI_GELU, FM, FN, WM, EROWS, ESTR, true>(pe, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g, nullptr, &lf);
+    if (p.epi == EPI_GELU && (p.a_fmt & 256)) epilogue_rows_bf16x8b<EPI_GELU, FM, FN, WM, EROWS, ESTR, true>(pe, acc, ew, m0 + wm, n0 + wn, lane, t, g, nullptr, &lf);
+    else if (p.epi == EPI_GELU) epilogue_rows_bf16x8<EPI_GELU, FM, FN, WM, EROWS, ESTR, true>(pe, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g, nullptr, &lf);
     else epilogue_rows_bf16_plain<FM, FN, WM, true>(pe, Cptr, acc, reinterpret_cast<char*>(ew), m0 + wm, n0 + wn, lane, t, g, &lf);
     GTS(3);
     return;
@@ -1019,12 +1127,15 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
                                                                                    : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));  // 16-byte row segments
   if (p.c_dtype == CSMAE_BF16) {
+#define EPI_CALL8B(E_) epilogue_rows_bf16x8b<E_, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g, srow)
     if (wide && p.epi == EPI_NONE && p.q_out == nullptr)
       epilogue_rows_bf16_plain<FM, FN, WM>(p, Cptr, acc, reinterpret_cast<char*>(ew), m0 + wm, n0 + wn, lane, t, g);
+    else if (wide && (p.a_fmt & 256)) { if (p.epi == EPI_GELU) EPI_CALL8B(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8B(EPI_DGELU); else EPI_CALL8B(EPI_RESID); }   // buffer addressing (bit 8 of a_fmt: set by the host when the sizes allow it)
     else if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
     else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
     else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
     else EPI_CALL(bf16_t, EPI_NONE);
+#undef EPI_CALL8B
   } else {
     if (p.epi == EPI_GELU) EPI_CALL(float, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(float, EPI_DGELU);
     else if (p.epi == EPI_RESID) EPI_CALL(float, EPI_RESID); else EPI_CALL(float, EPI_NONE);
@@ -1497,6 +1608,12 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
   p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;
+  // buffer-addressed epilogue (epilogue_rows_bf16x8b): bit 8 of a_fmt (the field is the fp8 kernels' otherwise).  A lane's 8 columns are valid as a
+  // whole, and a byte offset up to 256 rows past the end of any tensor the epilogue touches must not wrap (rows beyond M are range-checked away)
+  if (dtype == CSMAE_BF16 && c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll &&
+      (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) && ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) &&
+      !getenv("CSMAE_EPI_POINTERS"))   // (A/B aid: the pointer-addressed epilogues)
+    p.a_fmt |= 256;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMAE_BF16) {
     CSMAE_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "csmae_gemm(bf16): lda and ldb must be multiples of 8 (lda=%lld ldb=%lld)", lda, ldb);
