@@ -157,6 +157,12 @@ struct PieceDesc {
   }
 };
 
+// buffer resources for the epilogues that address their tensors by 32-bit byte offsets (rows beyond the end are dropped by the range check)
+typedef __amdgpu_buffer_rsrc_t brsrc_t;
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ brsrc_t buf_rsrc(const void* ptr, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)(unsigned)bytes, 0x00020000);
+}
 // Row-segment epilogue.  vmcnt is one in-order counter for loads AND stores on gfx9/CDNA: a residual / aux load issued after a
 // store cannot be consumed before that store has been acknowledged by memory (~2 us under load).  The first version of this
 // epilogue interleaved "load, add, store" per fragment and spent 45 % of the GEMM time in those waits.  So every global load of
@@ -449,11 +455,6 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
 // 32-bit add per pass, rows beyond M are dropped by the hardware's range check, columns beyond N are marked out of range once per tile.
 // Requirements (checked by the caller): N % 8 == 0 (a lane's 8 columns are valid or not as a whole), (M + 256) rows of every tensor < 4 GiB,
 // no fused fp8 copy.  Same arithmetic, same bytes as epilogue_rows_bf16x8.
-typedef __amdgpu_buffer_rsrc_t brsrc_t;
-typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ brsrc_t buf_rsrc(const void* ptr, long long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)(unsigned)bytes, 0x00020000);
-}
 template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR, bool LNF = false>
 __device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g,
                                                       float* srow = nullptr, const LnFoldRegs<FN, FM>* lf = nullptr) {
@@ -568,6 +569,8 @@ __device__ __forceinline__ void epilogue_rows_bf16_plain(const GemmArgs& p, void
   const int gn = nbase + col;
   const bool ok0 = gn < p.N, ok1 = gn + 4 < p.N;
   bf16_t* C = reinterpret_cast<bf16_t*>(Cptr);
+  // (buffer addressing — one add per pass, no row compare — measured 0.17 ms per step SLOWER for this epilogue, which has no arithmetic to
+  // speak of and is bound by store issue: it pays in the VALU-bound row-segment epilogues only, epilogue_rows_bf16x8b)
 #pragma unroll
   for (int part = 0; part < NPART; ++part) {
 #pragma unroll
@@ -1321,7 +1324,12 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_kernel(GemmArgs p) {
   const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
                                                                                    : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));
   if (p.c_dtype == CSMAE_BF16) {
-    if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
+    if (wide && (p.a_fmt & 256) && p.q_out == nullptr) {   // buffer addressing (epilogue_rows_bf16x8b)
+      if (p.epi == EPI_GELU) epilogue_rows_bf16x8b<EPI_GELU, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+      else if (p.epi == EPI_DGELU) epilogue_rows_bf16x8b<EPI_DGELU, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+      else if (p.epi == EPI_RESID) epilogue_rows_bf16x8b<EPI_RESID, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+      else epilogue_rows_bf16x8b<EPI_NONE, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+    } else if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
     else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
     else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
     else EPI_CALL(bf16_t, EPI_NONE);
@@ -1459,7 +1467,12 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_pipe_kernel(GemmArgs p) {
   const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
                                                                                    : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));
   if (p.c_dtype == CSMAE_BF16) {
-    if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
+    if (wide && (p.a_fmt & 256) && p.q_out == nullptr) {   // buffer addressing (epilogue_rows_bf16x8b)
+      if (p.epi == EPI_GELU) epilogue_rows_bf16x8b<EPI_GELU, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+      else if (p.epi == EPI_DGELU) epilogue_rows_bf16x8b<EPI_DGELU, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+      else if (p.epi == EPI_RESID) epilogue_rows_bf16x8b<EPI_RESID, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+      else epilogue_rows_bf16x8b<EPI_NONE, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g);
+    } else if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else if (p.epi == EPI_RESID) EPI_CALL8(EPI_RESID); else EPI_CALL8(EPI_NONE); }
     else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
     else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
     else EPI_CALL(bf16_t, EPI_NONE);
@@ -1495,6 +1508,9 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
   p.ktiles = cdiv(K, 128); p.ktiles_per_split = p.ktiles;
   p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
   p.dq_a = dq_a; p.dq_b = dq_b; p.a_fmt = a_fmt; p.aux_q8 = q8;
+  if (c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll && (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) &&
+      ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) && !getenv("CSMAE_EPI_POINTERS"))
+    p.a_fmt |= 256;   // buffer-addressed epilogue allowed (see gemm_core)
   p.q_out = reinterpret_cast<unsigned char*>(q_out); p.ldq = ldq; p.q_fmt = q_fmt; p.q_amax_prev = q_amax_prev; p.q_amax_next = q_amax_next; p.q_dq = q_dq;
   if (q_out) {   // (the fp8 copy leaves through the 16-byte-row epilogue only)
     const bool wide = (ldc % 8 == 0) && (epilogue == EPI_NONE || (epilogue == EPI_RESID ? (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0) : (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0)));
