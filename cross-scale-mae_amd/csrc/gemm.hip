@@ -1009,12 +1009,16 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   read_b(1, 0, fb0);
   static_for<FM - 2>([&](auto ic) { constexpr int i = decltype(ic)::value + 2; read_a(0, 0, std::integral_constant<int, i>{}, fa[i]); });
   auto nxt = [](int s, int k) { s += k; return s >= NUNIT ? s - NUNIT : s; };
-  // MODE 0: fetch units 2j+5 (B of step j+2) and 2j+6 (A of step j+3), prefetch step j+1   1: fetch 2j+5 only   2: nothing left to
-  // fetch   3: last step (nothing to prefetch either)
+  // A step fetches the units of step j+2, spread over both of its halves (all eight waves issue their pieces at the same rows, and
+  // 64 pieces inside one half step run the CU's vector-memory path at ~90 % of what it moves: a piece then costs its wave ~100 clk):
+  // the A image (unit 2j+4, into the slot step j-1's B image left at its barrier) one piece per second row of the FIRST half, the
+  // B image (unit 2j+5, into the slot of this step's A image) after the barrier.
+  // MODE 0: both   1: first step (unit 4 came with the prologue): B image only   2: nothing left to fetch   3: last step (nothing
+  // to prefetch either)
   auto step = [&](int jabs, int sl, auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     constexpr bool more = MODE < 3;
-    const int sl1 = nxt(sl, 1), sl2 = nxt(sl, 2), sl3 = nxt(sl, 3);
+    const int sl1 = nxt(sl, 1), sl2 = nxt(sl, 2), sl3 = nxt(sl, 3), sl4 = nxt(sl, 4);
     read_b(sl1, 1, fb1);
     static_for<FM>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -1024,6 +1028,7 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
       }
       mma_row(i, fa[i], fb0);
       read_a(sl, 1, ic, fa[i]);
+      if (MODE == 0 && (i & 1) && (i >> 1) < PPA) dma_a(sl4, jabs + 2, i >> 1);
       __builtin_amdgcn_sched_barrier(0);
     });
     if (USE_ASM) wait_ab(std::integral_constant<int, W1>{}, fa[0], fa[1], fb1);
@@ -1036,26 +1041,21 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (more) { read_a(sl2, 0, std::integral_constant<int, 0>{}, fa[0]); read_a(sl2, 0, std::integral_constant<int, 1>{}, fa[1]); read_b(sl3, 0, fb0); }
-    // the PPU + PPA pieces of the two units: one per remaining row, the surplus right here
-    constexpr int NPC = PPU + PPA, FIRST = NPC - (FM - 2);
-    auto piece = [&](int pc) {
-      if (pc < PPU) { if (MODE <= 1) dma_b(sl, jabs + 2, pc); }
-      else { if (MODE == 0) dma_a(sl1, jabs + 3, pc - PPU); }
-    };
-#pragma unroll
-    for (int pc = 0; pc < FIRST; ++pc) piece(pc);
-    __builtin_amdgcn_sched_barrier(0);
+    // the PPU pieces of the B image: spread over the FM - 2 remaining rows (the last one takes what is left)
     static_for<FM - 2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value + 2;
+      constexpr int i = decltype(ic)::value + 2, r = i - 2, NR = FM - 2;
       mma_row(i, fa[i], fb1);
       if (more) read_a(sl2, 0, std::integral_constant<int, i>{}, fa[i]);
-      piece(FIRST + i - 2);
+      if (MODE <= 1) {
+#pragma unroll
+        for (int pc = r * PPU / NR; pc < (r + 1) * PPU / NR; ++pc) dma_b(sl, jabs + 2, pc);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
   int j = 0, sl = 0;
-  for (; j < nsteps - 3; ++j, sl = nxt(sl, 2)) step(kt_begin + j, sl, std::integral_constant<int, 0>{});
-  if (nsteps >= 3) { step(kt_begin + j, sl, std::integral_constant<int, 1>{}); ++j; sl = nxt(sl, 2); }
+  if (nsteps >= 3) { step(kt_begin, 0, std::integral_constant<int, 1>{}); j = 1; sl = 2; }
+  for (; j < nsteps - 2; ++j, sl = nxt(sl, 2)) step(kt_begin + j, sl, std::integral_constant<int, 0>{});
   if (nsteps >= 2) { step(kt_begin + j, sl, std::integral_constant<int, 2>{}); ++j; sl = nxt(sl, 2); }
   step(kt_begin + j, sl, std::integral_constant<int, 3>{});
   GTS(2);
