@@ -137,6 +137,10 @@ __device__ __forceinline__ void lds_dma16(i4_t rsrc, unsigned voffset, const voi
   const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(const char, lds_dst));
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voffset), "s"(rsrc) : "memory");
 }
+// the same with the LDS destination as a (wave-uniform) LDS byte address: no generic -> LDS pointer cast (four scalar instructions per piece)
+__device__ __forceinline__ void lds_dma16u(i4_t rsrc, unsigned voffset, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rsrc) : "memory");
+}
 
 template <bool TR, int W>   // staging descriptor of one 1-KiB DMA piece of an operand image
 struct PieceDesc {
@@ -839,7 +843,6 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = lane & 15, g = lane >> 4;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int Kdim = p.K;
   void* Cptr = (!GROUP && p.epi == EPI_SPLIT) ? static_cast<void*>(reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride) : p.C;
 
   GTS(0);
@@ -869,20 +872,20 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
     bvo[1] = (unsigned)(((long long)(w * 8 + l5) * p.ldb + n0 + tr_ch(1) * 8) * 2);
   }
   const unsigned aqs = (unsigned)((TA ? 2 : 8) * p.lda * 2), bqs = (unsigned)((TB ? 2 : 8) * p.ldb * 2);  // advance per piece
-  const int arow = m0 + w * (PPA * 8) + l3, brow = n0 + w * 32 + l3, krow = w * 8 + l5;
   const int dbg = p.force_cfg;  // tuning aid (csmae_gemm_force_tile): 16 = main loop only
   // piece q of this wave's share of the A / B image of K step j (absolute), into ring slot `slot`
+  // No predicate per piece: the operands' buffer resources end with their last row (gemm_core), so rows beyond M / N and — K-strided
+  // images — k-rows beyond K are out of range and come back as zeros; K-contiguous operands are only routed here with K % 64 == 0 (a
+  // chunk beyond K would be the start of the next row, which is in range).  A piece is then ONE vector add (lane offset + the uniform
+  // K-step / piece advance) and three scalar instructions in front of its buffer_load: the loop is bound by instruction issue.
+  const unsigned ldsA = (unsigned)(size_t)LDS_PTR(char, smem) + (unsigned)(w * PPA) * 1024u, ldsB = (unsigned)(size_t)LDS_PTR(char, smem) + (unsigned)(w * PPU) * 1024u;
   auto dma_a = [&](int slot, int j, int q) {
     if (GEMM_ABL & 2) return;
-    const bool ok = !TA ? ((arow + q * 8 < p.M) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
-    const unsigned o = ok ? avo[q & 1] + ((unsigned)j * kstepA + (unsigned)q * aqs) : OOB_OFF;
-    lds_dma16(rsA, o, smem + slot * UNIT + (w * PPA + q) * 1024);
+    lds_dma16u(rsA, avo[q & 1] + ((unsigned)j * kstepA + (unsigned)q * aqs), ldsA + (unsigned)(slot * UNIT + q * 1024));
   };
   auto dma_b = [&](int slot, int j, int q) {
     if (GEMM_ABL & 2) return;
-    const bool ok = !TB ? ((brow + q * 8 < p.N) & (j * 64 + kc < Kdim)) : (j * 64 + krow + 2 * q < Kdim);
-    const unsigned o = ok ? bvo[q & 1] + ((unsigned)j * kstepB + (unsigned)q * bqs) : OOB_OFF;
-    lds_dma16(rsB, o, smem + slot * UNIT + (w * PPU + q) * 1024);
+    lds_dma16u(rsB, bvo[q & 1] + ((unsigned)j * kstepB + (unsigned)q * bqs), ldsB + (unsigned)(slot * UNIT + q * 1024));
   };
 
   f4_t acc[FM][FN];
@@ -1659,6 +1662,12 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
     if (cfg > 5) cfg = 4;
     if (cfg == 5 && (transA || splitk != 1)) cfg = 4;
     if (cfg == 4 && transA && !transB) cfg = 2;  // (no 64-wide-K instantiation for K-strided A with K-contiguous B: unused by the step)
+    // the pipelined kernel fetches without per-piece predicates (k64_tile): K-contiguous operands need whole 64-wide K steps, and a byte offset up
+    // to one tile past the end of an operand must not wrap
+    if (cfg >= 4 && ((!(transA && transB) && K % 64 != 0) || ((transA ? K + 64 : M + 256) * lda * 2 >= 0xFFFFFFF0ll) || ((transB ? K + 64 : N + 256) * ldb * 2 >= 0xFFFFFFF0ll))) {
+      CSMAE_REQUIRE(!ln, "csmae_gemm (LayerNorm fold): K must be a multiple of 64");
+      cfg = 2;
+    }
     if (cfg >= 4) p.ktiles = cdiv(K, 64);
     (void)stg;
     const int bm = cfg == 0 ? 128 : (cfg == 5 ? 192 : 256), bn = cfg >= 2 ? 256 : 128;
