@@ -275,6 +275,7 @@ class Engine:
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
+        self._fwd_lead = int(os.environ.get("CSMAE_FWD_LEAD", "0"))   # samples the main stream's forward chunk takes beyond half of the batch
         self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
         # 128 workgroups = 4 / 8 whole K slices of its 32- and 16-tile launches (160 -> 128: -0.15 .. -0.3 ms per step; 64: +1.4 ms)
@@ -737,11 +738,15 @@ class Engine:
             while len(self._fwd_streams) < nch - 1:
                 self._fwd_streams.append(self.side if not self._fwd_streams else torch.cuda.Stream())
             per = B2 // nch
+            # the main stream starts first (the other ones wait for the stem) and would idle at the join: it takes `_fwd_lead` samples more
+            # than its share (chunks are sample ranges: attention, LayerNorm and the GEMM rows do not care where a view ends)
+            lead = self._fwd_lead if (nch == 2 and not self.fp8 and 0 < per + self._fwd_lead < B2) else 0   # (fp8: the staging buffers of a chunk hold half a batch)
+            cuts = [0, per + lead] + [k * per for k in range(2, nch)] + [B2]
             for so in self._fwd_streams[: nch - 1]:
                 so.wait_stream(main)         # (the stem; and the previous step's readers of the workspace)
             evs = []
-            gens = [trunk(0, per, st, main, evs)] + [trunk(k * per, per, self._fwd_streams[k - 1].cuda_stream, self._fwd_streams[k - 1], evs)
-                                                      for k in range(1, nch)]
+            gens = [trunk(0, cuts[1], st, main, evs)] + [trunk(cuts[k], cuts[k + 1] - cuts[k], self._fwd_streams[k - 1].cuda_stream, self._fwd_streams[k - 1], evs)
+                                                          for k in range(1, nch)]
             if os.environ.get("CSMAE_FWD_SEQ_ENQUEUE"):  # tuning aid: one trunk after the other, as before
                 for g in gens:
                     for _ in g:

@@ -1365,15 +1365,14 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_pipe_kernel(GemmArgs p) {
   const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   // DMA: piece = 8 rows x 128 B; lane -> row (lane >> 3), physical chunk (lane & 7) = logical chunk ^ (row & 7); wave w owns rows 32 w .. 32 w + 31 of an image
   const int l3 = lane >> 3, kc = ((lane & 7) ^ l3) * 16;
-  const int arow = m0 + w * 32 + l3, brow = n0 + w * 32 + l3;
-  const unsigned avo = (unsigned)((long long)arow * p.lda + kc), bvo = (unsigned)((long long)brow * p.ldb + kc);
+  const unsigned avo = (unsigned)((long long)(m0 + w * 32 + l3) * p.lda + kc), bvo = (unsigned)((long long)(n0 + w * 32 + l3) * p.ldb + kc);
+  // (no predicate per piece, as in k64_tile: rows beyond M / N are beyond the buffer resources' ends, and the host routes only K % 128 == 0 here)
+  const unsigned ldsW = (unsigned)(size_t)LDS_PTR(char, smem) + (unsigned)(w * PP) * 1024u;
   auto dma_a = [&](int slot, int j, int q) {
-    const bool ok = (arow + q * 8 < p.M) & (j * 128 + kc < p.K);
-    lds_dma16(rsA, ok ? avo + (unsigned)(j * 128) + (unsigned)(q * 8 * p.lda) : OOB_OFF, smem + slot * UNIT + (w * PP + q) * 1024);
+    lds_dma16u(rsA, avo + ((unsigned)(j * 128) + (unsigned)(q * 8 * p.lda)), ldsW + (unsigned)(slot * UNIT + q * 1024));
   };
   auto dma_b = [&](int slot, int j, int q) {
-    const bool ok = (brow + q * 8 < p.N) & (j * 128 + kc < p.K);
-    lds_dma16(rsB, ok ? bvo + (unsigned)(j * 128) + (unsigned)(q * 8 * p.ldb) : OOB_OFF, smem + slot * UNIT + (w * PP + q) * 1024);
+    lds_dma16u(rsB, bvo + ((unsigned)(j * 128) + (unsigned)(q * 8 * p.ldb)), ldsW + (unsigned)(slot * UNIT + q * 1024));
   };
   f4_t acc[FM][FN];
 #pragma unroll
@@ -1436,14 +1435,17 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_pipe_kernel(GemmArgs p) {
 #pragma unroll
       for (int jj = 0; jj < FN; ++jj) FP8_MMA(i, jj);
       if (more) read_a(sa, ic);
-      // the 2 x PP pieces of the two freed units over the first PP rows: unit 2 j + 5 (B of step j + 2) into this step's A slot, 2 j + 6 into its B slot
-      if (i < PP) { if (MODE <= 1) dma_b(sl, j + 2, i); if (MODE == 0) dma_a(sb_cur, j + 3, i); }
+      // the 2 x PP pieces of the two freed units, ONE per row / column group: unit 2 j + 5 (B of step j + 2) into this step's A slot first — the
+      // next step's head needs it, and its `vmcnt(PP)` leaves exactly the PP younger pieces of unit 2 j + 6 (into this step's B slot) in flight
+      if (i < PP) { if (MODE <= 1) dma_b(sl, j + 2, i); }
+      else if (MODE == 0) dma_a(sb_cur, j + 3, i - PP);
       __builtin_amdgcn_sched_barrier(0);
     });
     static_for<FN>([&](auto jc) {   // the last two rows column by column: B fragment jj retires here and is re-read for the next step
       constexpr int jj = decltype(jc)::value;
       FP8_MMA(FM - 2, jj); FP8_MMA(FM - 1, jj);
       if (more) read_b(sb, jc);
+      if (MODE == 0 && jj + (FM - 2 - PP) < PP) dma_a(sb_cur, j + 3, jj + (FM - 2 - PP));
       __builtin_amdgcn_sched_barrier(0);
     });
     if (more) { read_a(sa, std::integral_constant<int, FM - 2>{}); read_a(sa, std::integral_constant<int, FM - 1>{}); }
@@ -1521,7 +1523,9 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
                   "csmae_gemm_fp8: the fused fp8 copy needs a bf16 output with 8-element aligned rows and the three scale pointers");
   }
   dim3 grid(p.tiles_m * p.tiles_n);
-  static const bool two_stage = getenv("CSMAE_FP8_TWO_STAGE") != nullptr;   // A/B aid: the first (two-stage, barrier-per-step) kernel
+  static const bool two_stage_env = getenv("CSMAE_FP8_TWO_STAGE") != nullptr;   // A/B aid: the first (two-stage, barrier-per-step) kernel
+  // the pipelined kernel fetches whole 128-byte K steps without predicates; a byte offset one tile past an operand's end must not wrap
+  const bool two_stage = two_stage_env || K % 128 != 0 || (M + 256) * lda >= 0xFFFFFFF0ll || (N + 256) * ldb >= 0xFFFFFFF0ll;
   if (two_stage) {
     if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_fp8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);

@@ -7,4 +7,5 @@ export TMPDIR=/tmp
 db=$(find /tmp/prof_$tag -name '*.db' | head -1)
 python tools/rocpd_stats.py $db $out/kernel_stats.txt > /dev/null
 python tools/step_timeline.py $db > $out/timeline.txt 2>&1
-head -6 $out/timeline.txt; tail -1 $out/timeline.txt; head -24 $out/kernel_stats.txt
+python tools/step_dump.py $db $out/step_dump.txt > /dev/null 2>&1
+head -6 $out/timeline.txt; tail -1 $out/timeline.txt
