@@ -63,6 +63,8 @@ _SIGNATURES = {
     "csmae_latent_grad_finish": [I, L, I, I, P, P, F, P, P],
     "csmae_loss_finalize": [L, I, P, P, F, P, F, P, F, P, I, P, P],
     "csmae_augment_u8": [L, I, I, I, I, P, P, P, P, P, P],
+    "csmae_next_launch_event": [P],
+    "csmae_flush_launch_event": [P],
     "csmae_adamw": [L, P, P, P, P, P, P, P, F, F, F, F, F, F, P, P, P],
     "csmae_gate_accumulate": [P, P, I, P],
     "csmae_clip_grad_norm": [L, P, F, P, P, P],
@@ -94,7 +96,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = sig
         fn.restype = c_int
-    if lib.csmae_abi_version() != 3:
+    if lib.csmae_abi_version() != 4:
         raise CsmaeError("libcsmae_hip ABI version mismatch")
     _lib = lib
     return lib

@@ -17,6 +17,7 @@ generator for the masking noise, the CPU generator for the crop box — Appendix
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import weakref
@@ -275,6 +276,7 @@ class Engine:
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
+        self._ev_carry = os.environ.get("CSMAE_EV_CARRY", "1") != "0"   # A/B aid: 0 = events recorded behind the kernels, as before
         self._fwd_lead = int(os.environ.get("CSMAE_FWD_LEAD", "0"))   # samples the main stream's forward chunk takes beyond half of the batch
         self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
@@ -466,7 +468,7 @@ class Engine:
         y = S["y1"][0] if which == 1 else S["y2"][0]
         ops.layernorm_fwd(x, P(f"{pre}norm{which}.weight"), P(f"{pre}norm{which}.bias"), y, S["st_scratch"][0], S["st_scratch"][1], st=st)
 
-    def _dw_group(self, items, slots=None, pre=()):
+    def _dw_group(self, items, slots=None, pre=(), ready=None):
         """Weight gradients of several Linear layers over the same tokens, [(dy, x, name)], in one launch (csmae_gemm_dw_group: the
         products share the chip, K slices are folded inside the kernel, the result goes straight into the gradient buffer).
 
@@ -487,8 +489,11 @@ class Engine:
             grp.launch(256, st=self.st)   # nothing runs beside the launch there, so it gets the whole chip like the other layouts' kernels
             return                        # (the 160-workgroup setting is a co-scheduling choice of the overlapped step, not a kernel property)
         side = self.side
-        ev = self._event()
-        ev.record(self.main)
+        if ready is not None:   # the kernel that made the launch's last operand carries the event itself (ops.launch_done): no marker on the main stream
+            ev = ready
+        else:
+            ev = self._event()
+            ev.record(self.main)
         side.wait_event(ev)
         for S_, i_, pre_, which in pre:   # (LayerNorm fold) operands this launch reads that the forward pass did not keep
             self._renorm(S_, i_, pre_, which, side.cuda_stream)
@@ -515,7 +520,9 @@ class Engine:
 
     def _event(self):
         if self._ev_i == len(self._events):
-            self._events.append(torch.cuda.Event())
+            e = torch.cuda.Event()
+            e.record()   # (torch creates the HIP event at its first record: ops.launch_done needs the handle)
+            self._events.append(e)
         self._ev_i += 1
         return self._events[self._ev_i - 1]
 
@@ -613,10 +620,15 @@ class Engine:
         self._fp8_cur = None
         kd = self._fp8_alloc()
         ed = self._emit(kd, ws.q_b[0], M, 4 * Dm, 1) if self.fp8 else None
-        self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
+        # the kernels whose outputs a weight-gradient launch waits for carry that launch's event themselves (an event recorded behind them
+        # is a marker packet: ~5 us of idle main stream each, two per block)
+        carried = self._ev_carry and ops._timer is None and not os.environ.get("CSMAE_DW_MAIN")
+        ev1 = self._event() if (carried and mode == "half") else None
+        with (ops.launch_done(ev1, st) if ev1 is not None else contextlib.nullcontext()):
+            self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
         slots = self._dw_slots_ed[0 if S is ws.enc else 1] if self._dw_slots_ed else None
         if mode == "half":
-            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, pre=re2)
+            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, pre=re2, ready=ev1)
         elif mode == "none":
             self._dw(dpre, y2, pre + "mlp.fc1", pre=re2)
         self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
@@ -632,12 +644,14 @@ class Engine:
             self._dw(nxt, S["o"][i], pre + "attn.proj")
         self._mm(nxt, pre + "attn.proj.weight", t1, trans_b=True, st=st, site=kn, a8=en[0] if en else None)
         self._guard_write(dqkv)
-        ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
+        ev2 = self._event() if (carried and mode in ("half", "block")) else None
+        with (ops.launch_done(ev2, st) if ev2 is not None else contextlib.nullcontext()):
+            ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
         if mode == "block":
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1"),
-                            (nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re2 + re1)
+                            (nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re2 + re1, ready=ev2)
         elif mode == "half":
-            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re1)
+            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re1, ready=ev2)
         else:
             self._dw(dqkv, y1, pre + "attn.qkv", pre=re1)
         self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st)

@@ -64,6 +64,22 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class launch_done:
+    """`with launch_done(ev, st): <one op>` — the op's kernel carries the torch event `ev` as its own completion signal (csmae_next_launch_event)
+    instead of a marker packet recorded behind it on stream `st`; ops whose launch site does not support that get the plain record.  `ev` must
+    have been recorded once before (torch creates the HIP event at its first record)."""
+
+    def __init__(self, ev, st):
+        self.h, self.st = ev.cuda_event, st
+
+    def __enter__(self):
+        check(load().csmae_next_launch_event(self.h), "csmae_next_launch_event")
+
+    def __exit__(self, *exc):
+        check(load().csmae_flush_launch_event(self.st), "csmae_flush_launch_event")
+        return False
+
+
 def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, splitk=1, st=None):
     """out[M,N] (+)= A(m,k) B(k,n).  a: [M,K] ([K,M] if trans_a); b: [N,K] ([K,N] if trans_b)."""
     K, M = (a.shape[0], a.shape[1]) if trans_a else (a.shape[1], a.shape[0])

@@ -21,7 +21,22 @@ int csmae_check_launch(const char* what) {
 }
 
 extern "C" const char* csmae_last_error(void) { return g_err; }
-extern "C" int csmae_abi_version(void) { return 3; }
+extern "C" int csmae_abi_version(void) { return 4; }
+
+// ---- an event attached to the next launch (common.h: CSMAE_LAUNCH).  The reference has no counterpart: torch records events behind kernels
+// (autograd's stream hand-offs, DDP's bucket hooks — main_pretrain.py:417-421); here the weight-gradient stream of csmae_hip/engine.py waits for
+// the main chain's dX GEMM / attention backward through the kernel's own completion signal.
+thread_local hipEvent_t g_csmae_launch_event = nullptr;
+extern "C" int csmae_next_launch_event(void* hip_event) { g_csmae_launch_event = (hipEvent_t)hip_event; return CSMAE_OK; }
+// after the launch: if its launch site did not take the event (not every kernel goes through CSMAE_LAUNCH), record it the plain way
+extern "C" int csmae_flush_launch_event(void* stream) {
+  hipEvent_t ev = g_csmae_launch_event;
+  if (!ev) return CSMAE_OK;
+  g_csmae_launch_event = nullptr;
+  hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
+  if (e != hipSuccess) { csmae_set_error("csmae_flush_launch_event: %s", hipGetErrorString(e)); return CSMAE_ERR_LAUNCH; }
+  return CSMAE_OK;
+}
 #ifndef CSMAE_SRC_HASH
 #define CSMAE_SRC_HASH "unknown"
 #endif

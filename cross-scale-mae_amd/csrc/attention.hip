@@ -895,13 +895,13 @@ static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void
   static const bool two_sweeps = getenv("CSMAE_ATTN_BWD_2SWEEP") != nullptr;  // tuning aid: one key pair per wave and sweep (the first single-pass version)
   constexpr bool KP2_OK = HD <= 32 && NKF >= 6 && NKF <= 16 && AttnBwd1p<HD, NKF>::LDS <= 160 * 1024;
   if (KP2_OK && !two_pass && !two_sweeps)
-    hipLaunchKernelGGL((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+    CSMAE_LAUNCH((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
   else if (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 && NKF >= 6 && !two_pass)  // (<= 64 tokens: fewer key pairs than waves, the two-pass split is faster)
-    hipLaunchKernelGGL((attn_bwd1p_bf16<HD, (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
+    CSMAE_LAUNCH((attn_bwd1p_bf16<HD, (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
   else
-    hipLaunchKernelGGL((attn_bwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
+    CSMAE_LAUNCH((attn_bwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
 }
 
 // (head_dim bucket, key-fragment count) combinations whose LDS images fit 160 KiB in the backward kernel

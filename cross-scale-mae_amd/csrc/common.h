@@ -32,6 +32,17 @@ __device__ __forceinline__ s8_t join_s4(s4_t lo, s4_t hi) {
 // ---- error plumbing (thread-local message; see include/csmae.h csmae_last_error)
 void csmae_set_error(const char* fmt, ...);
 int csmae_check_launch(const char* what);
+// Completion event of the NEXT kernel launch of this host thread (csmae_next_launch_event).  A launch site that goes through CSMAE_LAUNCH
+// attaches the event to its dispatch packet (hipExtLaunchKernelGGL's stopEvent: the packet's own completion signal) instead of leaving the
+// caller to put a marker packet behind the kernel — a marker costs the stream it is recorded on 3-5 us (tools/event_probe.hip).
+#include <hip/hip_ext.h>
+extern thread_local hipEvent_t g_csmae_launch_event;
+#define CSMAE_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                        \
+  do {                                                                                                               \
+    hipEvent_t ev_ = g_csmae_launch_event;                                                                           \
+    if (ev_) { g_csmae_launch_event = nullptr; hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev_, 0, __VA_ARGS__); } \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                        \
+  } while (0)
 #define CSMAE_REQUIRE(cond, ...)                     \
   do {                                               \
     if (!(cond)) {                                   \

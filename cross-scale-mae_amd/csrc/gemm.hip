@@ -1529,8 +1529,8 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
   if (two_stage) {
     if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_fp8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
-  } else if (a_fmt == 0) hipLaunchKernelGGL(gemm_fp8_pipe_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gemm_fp8_pipe_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
+  } else if (a_fmt == 0) CSMAE_LAUNCH(gemm_fp8_pipe_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, p);
+  else CSMAE_LAUNCH(gemm_fp8_pipe_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, p);
   return csmae_check_launch("csmae_gemm_fp8");
 }
 
@@ -1691,11 +1691,11 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
       else if (cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<192, 2>), grid, dim3(512), 0, st, p, la);
       else hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<256, 2>), grid, dim3(512), 0, st, p, la);
     }
-    else if (cfg == 5 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false, 192>), grid, dim3(512), 0, st, p);
-    else if (cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, true, 192>), grid, dim3(512), 0, st, p);
-    else if (cfg == 4 && transA) hipLaunchKernelGGL((gemm_bf16_k64_kernel<true, true>), grid, dim3(512), 0, st, p);
-    else if (cfg == 4 && !transB) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, false>), grid, dim3(512), 0, st, p);
-    else if (cfg == 4) hipLaunchKernelGGL((gemm_bf16_k64_kernel<false, true>), grid, dim3(512), 0, st, p);
+    else if (cfg == 5 && !transB) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, false, 192>), grid, dim3(512), 0, st, p);
+    else if (cfg == 5) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, true, 192>), grid, dim3(512), 0, st, p);
+    else if (cfg == 4 && transA) CSMAE_LAUNCH((gemm_bf16_k64_kernel<true, true>), grid, dim3(512), 0, st, p);
+    else if (cfg == 4 && !transB) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, false>), grid, dim3(512), 0, st, p);
+    else if (cfg == 4) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, true>), grid, dim3(512), 0, st, p);
     else if (!transA && !transB) { LAUNCH_CFG(false, false) }
     else if (!transA && transB) { LAUNCH_CFG(false, true) }
     else if (transA && transB) { LAUNCH_CFG(true, true) }

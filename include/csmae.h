@@ -34,6 +34,14 @@ const char* csmae_last_error(void);
 int csmae_abi_version(void);
 const char* csmae_source_hash(void);   /* sha256 of the kernel sources the library was built from (tools/csrc_hash.py): profiles are keyed to it */
 
+/* ---- completion event of the NEXT kernel launch of the calling host thread (ABI version 4).  The reference hands work between streams through
+ * events that torch records BEHIND a kernel (autograd's stream hand-offs; DistributedDataParallel's bucket hooks, main_pretrain.py:417-421);
+ * a recorded event is a marker packet that costs the recording stream 3-5 us.  csmae_next_launch_event(ev) makes the next csmae_gemm /
+ * csmae_gemm_fp8 (pipelined kernels) / csmae_attn_bwd (bf16) launch carry `ev` (a hipEvent_t) as its dispatch packet's completion signal
+ * instead; csmae_flush_launch_event(stream) records it the plain way when that launch did not take it (other kernels), nullptr clears it.  */
+int csmae_next_launch_event(void* hip_event);
+int csmae_flush_launch_event(void* stream);
+
 /* ---- dense contractions: nn.Linear of timm Block / decoder_embed / decoder_pred / predictor and their backward
  * (timm 0.4.12 Attention.qkv/.proj, Mlp.fc1/.fc2 — call sites models_mae/MAE_ViT_Baseline.py:160-188,270,295;
  *  models_mae/MLP.py:6,9).  C[M,N] = sum_k A(m,k) B(k,n); transX = 0: K contiguous ([M,K] / [N,K]); 1: K strided ([K,M] / [K,N]).

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/csmae.h but not exported"
     assert set(decl) == set(csmae_hip.exported_symbols())
     lib.csmae_abi_version.restype = ctypes.c_int
-    assert lib.csmae_abi_version() == 3
+    assert lib.csmae_abi_version() == 4
 
 
 def test_binding_arity_matches_header():
