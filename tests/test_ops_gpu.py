@@ -303,6 +303,49 @@ def test_attention_fwd_bwd(ops, geom, dtype):
     assert_close(dqkv, q32.grad, tol, tol * max(gscale, 1.0), f"attn dqkv {geom}")
 
 
+@pytest.mark.parametrize("case", ["k64 gemm", "small gemm", "attention backward"])
+def test_launch_carried_event_orders_a_second_stream(ops, case):
+    """csmae_next_launch_event: the kernel carries the event as its dispatch packet's completion signal (pipelined GEMM, bf16 attention
+    backward) or — launch sites that do not support it — gets the plain record from csmae_flush_launch_event.  Either way a second stream
+    that waits for the event must see the kernel's output (what torch's `event.record()` behind the kernel guarantees: the hand-off the
+    weight-gradient stream of csmae_hip/engine.py relies on; autograd's stream hand-offs in the reference)."""
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record()                                   # (torch creates the HIP event at its first record)
+    spin = torch.empty(64 << 20, device="cuda")   # a long kernel in front, so that the launch is still queued when the second stream starts waiting
+    if case == "attention backward":
+        B, T, H, hd = 8, 197, 16, 32
+        D = H * hd
+        qkv = dev(rnd(B * T, 3 * D, seed=30).to(torch.bfloat16))
+        dout = dev(rnd(B * T, D, seed=31).to(torch.bfloat16))
+        out = torch.empty(B * T, D, device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(B, H, T, device="cuda")
+        ops.attn_fwd(qkv, out, lse, B, T, H, hd)
+        want = torch.empty(B * T, 3 * D, device="cuda", dtype=torch.bfloat16)
+        ops.attn_bwd(qkv, out, dout, lse, want, B, T, H, hd)
+        got = torch.zeros_like(want)
+        run = lambda: ops.attn_bwd(qkv, out, dout, lse, got, B, T, H, hd)
+    else:
+        M, N, K = (2048, 1024, 512) if case == "k64 gemm" else (96, 72, 40)
+        A, Bm = dev(rnd(M, K, seed=32).to(torch.bfloat16)), dev(rnd(N, K, seed=33).to(torch.bfloat16))
+        want = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, Bm, want)
+        got = torch.zeros_like(want)
+        run = lambda: ops.gemm(A, Bm, got)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got.zero_()
+        spin.fill_(1.0)
+        with ops.launch_done(ev, main.cuda_stream):
+            run()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            seen = got.clone()
+        side.synchronize()
+        assert torch.equal(seen, want), case
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("MD", [(37, 768), (200, 512), (9, 64), (5, 128), (16, 1024), (7, 1280)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
