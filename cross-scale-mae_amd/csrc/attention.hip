@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  TS(0);
   HeadStager<HD, TP, 256, 2> sg;
   sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
   const int nkp = (T + 31) >> 5;
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
     }
     lse2[r] = l2; dl[r] = acc;
   }
+  TS(1);
   sg.store(0, Qs); sg.store(1, Gs);
   const float c2 = scale * LOG2E;
   char* xw = xall + w * L::XB;
@@ -582,7 +584,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
 #pragma unroll
       for (int df = 0; df < DF; ++df) { dk[pi][jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; dv[pi][jj][df] = f4_t{0.f, 0.f, 0.f, 0.f}; }
   }
+  TS(2);
   __syncthreads();                          // staging, statistics and the cleared accumulator are visible
+  TS(3);
   for (int s = 0; s < nq; ++s) {
     int ip = w + s; if (ip >= nq) ip -= nq;
     const int q0 = 32 * ip;
@@ -647,7 +651,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
       }
     }
     __syncthreads();                        // the rows this wave updated belong to another wave in the next step
+    if (s == 0) TS(5);
   }
+  TS(4);
 #pragma unroll
   for (int pi = 0; pi < NPW; ++pi) {
 #pragma unroll
@@ -663,10 +669,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
       }
     }
   }
+  TS(10);
   for (int e = threadIdx.x; e < T * (HD / 4); e += blockDim.x) {
     const int q = e / (HD / 4), d = (e - q * (HD / 4)) * 4;
     if (d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d));
   }
+  TS(11);
 }
 
 // ------------------------------------------------------------------------------------------ fp32 (parity mode)
