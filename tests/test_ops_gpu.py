@@ -42,7 +42,8 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-SHAPES = [(128, 128, 64), (256, 384, 192), (104, 72, 40), (8, 16, 8), (1024, 768, 768), (640, 2304, 768), (200, 512, 2048)]
+SHAPES = [(128, 128, 64), (256, 384, 192), (104, 72, 40), (8, 16, 8), (1024, 768, 768), (640, 2304, 768), (200, 512, 2048),
+          (512, 512, 200), (304, 264, 328), (776, 512, 584)]   # (K not a multiple of 64 at M, N >= 256: routed past the predicate-free pipelined kernel)
 
 
 @pytest.mark.parametrize("mnk", SHAPES)
