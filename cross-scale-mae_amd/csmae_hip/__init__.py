@@ -35,6 +35,9 @@ _SIGNATURES = {
     "csmae_gemm_force_tile": [I],
     "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
+    "csmae_attn_resident": [I, I, I],
+    "csmae_attn_fwd_q": [I, L, I, I, I, P, P, P, P, I, P, P, P, P],
+    "csmae_attn_bwd_q": [I, L, I, I, I, P, P, P, P, P, P, I, P, P, P, P],
     "csmae_layernorm_fwd": [I, I, L, I, P, P, P, F, P, P, P, P, P, I, P, P, P, P],
     "csmae_layernorm_bwd": [I, I, I, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P, I, P, P, P, P],
     "csmae_ln_param_reduce": [I, L, I, P, L, L, P, P, P],

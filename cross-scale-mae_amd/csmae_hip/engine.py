@@ -235,6 +235,7 @@ class Engine:
         self._fp8_site = 0
         self._fp8_cur = None    # (site, fp8 bytes or None) of the residual gradient the next block's fc2-backward product reads
         self._fp8_fuse_lnb = not os.environ.get("CSMAE_FP8_NO_FUSE_LNB")
+        self._fp8_fuse_attn = not os.environ.get("CSMAE_FP8_NO_FUSE_ATTN")   # A/B aid: attention's fp8 copies by separate quantisation passes
         self._fp8_fuse = not os.environ.get("CSMAE_FP8_NO_FUSE")   # A/B aid: every fp8 operand through the separate quantisation pass
         if self.fp8:
             act_dtype = torch.bfloat16
@@ -567,8 +568,12 @@ class Engine:
         e1 = self._emit(k1, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
         ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, st=st)
         self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=ln, site=k1, a8=e1[0] if e1 else None)
-        ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, st=st)
-        self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0))
+        # (fp8 mode) attention leaves its output as fp8 bytes for attn.proj (q_a: y1 has been consumed by the qkv GEMM, y2 comes after proj)
+        ko = self._fp8_alloc()
+        eo = self._emit(ko, ws_q_a[ln], Mr, Dm, 0) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
+        ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, emit=eo, st=st)
+        self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0), site=ko,
+                 a8=eo[0] if eo else None)
         k2 = self._fp8_alloc()
         e2 = self._emit(k2, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
         ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], emit=e2, st=st)
@@ -645,8 +650,11 @@ class Engine:
         self._mm(nxt, pre + "attn.proj.weight", t1, trans_b=True, st=st, site=kn, a8=en[0] if en else None)
         self._guard_write(dqkv)
         ev2 = self._event() if (carried and mode in ("half", "block")) else None
+        # (fp8 mode) ... and dqkv for attn.qkv's backward (q_b[0]: dpre's copy has been consumed by fc1's backward GEMM)
+        kq = self._fp8_alloc()
+        eq = self._emit(kq, ws.q_b[0], M, 3 * Dm, 1) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
         with (ops.launch_done(ev2, st) if ev2 is not None else contextlib.nullcontext()):
-            ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, st=st)
+            ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, emit=eq, st=st)
         if mode == "block":
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1"),
                             (nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re2 + re1, ready=ev2)
@@ -654,7 +662,7 @@ class Engine:
             self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re1, ready=ev2)
         else:
             self._dw(dqkv, y1, pre + "attn.qkv", pre=re1)
-        self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st)
+        self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st, site=kq, a8=eq[0] if eq else None)
         self._guard_write(out)
         kx = self._fp8_alloc() if i > 0 else None     # the next block's fc2-backward reads `out`
         ex = self._emit(kx, ws.q_a[1], M, Dm, 1) if (self.fp8 and dres is None and self._fp8_fuse_lnb) else None

@@ -232,12 +232,25 @@ class DwGroup:
             _timer.end(("gemm_bf16" if self.dtype == BF16 else "gemm_f32") + "_TN", self.flops)
 
 
-def attn_fwd(qkv, out, lse, B, T, H, hd, st=None):
-    check(load().csmae_attn_fwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(lse), st if st is not None else stream()), "csmae_attn_fwd")
+def attn_resident(dtype_code, T, hd):
+    """True when (dtype, T, head_dim) runs the LDS-resident MFMA attention kernels (the ones that can emit an fp8 copy of their output)."""
+    return load().csmae_attn_resident(dtype_code, T, hd) == 1
 
 
-def attn_bwd(qkv, out, dout, lse, dqkv, B, T, H, hd, st=None):
-    check(load().csmae_attn_bwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), st if st is not None else stream()), "csmae_attn_bwd")
+def attn_fwd(qkv, out, lse, B, T, H, hd, emit=None, st=None):
+    """emit = (q_out uint8 [B*T, H*hd], fmt, amax_prev [64], amax_next [64], dq [1]): also write `out` as fp8 bytes for attn.proj's GEMM."""
+    if emit is None:
+        check(load().csmae_attn_fwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(lse), st if st is not None else stream()), "csmae_attn_fwd")
+    else:
+        check(load().csmae_attn_fwd_q(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(lse), *_emit_args(emit), st if st is not None else stream()), "csmae_attn_fwd_q")
+
+
+def attn_bwd(qkv, out, dout, lse, dqkv, B, T, H, hd, emit=None, st=None):
+    if emit is None:
+        check(load().csmae_attn_bwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), st if st is not None else stream()), "csmae_attn_bwd")
+    else:
+        check(load().csmae_attn_bwd_q(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), *_emit_args(emit), st if st is not None else stream()),
+              "csmae_attn_bwd_q")
 
 
 def _emit_args(emit):

@@ -84,9 +84,13 @@ __device__ __forceinline__ int pair_remap(int bid, int nblk) {
   return (bid & ~15) + 2 * (bid & 7) + ((bid >> 3) & 1);
 }
 
-template <int HD, int NKF>
+// EMIT (fp8 mode, csmae_attn_fwd_q / csmae_attn_bwd_q): the kernel also leaves its output as fp8 bytes for the GEMM that consumes it (attn.proj
+// forward: e4m3; attn.qkv backward: e5m2), quantised from the ROUNDED bf16 values with the amax of one step earlier — exactly what the separate
+// csmae_fp8_quantize pass over the bf16 tensor produced — and records the new amax.  Instantiations of their own: the bf16 step's kernels
+// carry none of it.
+template <int HD, int NKF, bool EMIT = false>
 __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                     float* __restrict__ lse, int T, int H, int D, int hd, float scale) {
+                                                     float* __restrict__ lse, int T, int H, int D, int hd, float scale, Fp8Emit em) {
   constexpr int TP = NKF * 16, KS = HD / 32, DF = HD / 16;
   // K and V of the head live in LDS (every wave reads all of them); a wave's Q fragments (its <= QB query blocks, needed by nobody
   // else) come straight from global memory into registers, fetched together with the staging loads: 36 instead of 54 KiB of LDS for
@@ -116,6 +120,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
     sg.store(0, Ks); sg.store(1, Vs);
   }
   __syncthreads();
+  float qmax = 0.f, qseen = 0.f;
+  const float qs = EMIT ? fp8_emit_scale(em, lane, qmax) : 1.f;
   const float c2 = scale * LOG2E;
   const int nqb = (T + 15) >> 4;
   constexpr int FIRST_PARTIAL = NKF <= 2 ? 0 : (NKF <= 6 ? NKF - 2 : (NKF == 14 ? 6 : 14));  // floor(T_min / 16) of the bucket dispatching to this NKF
@@ -162,17 +168,28 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
 #pragma unroll
       for (int s2 = 0; s2 < NKF / 2; ++s2) o = MFMA16(frag_cols_tr<HD>(Vs, 32 * s2, df * 16, t, g), fp[s2], o);
       int d = df * 16 + 4 * g;
-      if (q < T && d < hd) st4<bf16_t>(out + (row0 + q) * D + h * hd + d, o * inv);
+      if (q < T && d < hd) {
+        const long long at = (row0 + q) * D + h * hd + d;
+        st4<bf16_t>(out + at, o * inv);
+        if (EMIT) *reinterpret_cast<unsigned*>(em.q + at) = fp8_pack4(round4<bf16_t>(o * inv), qs, qmax, em.fmt, qseen);
+      }
     }
     if (g == 0 && q < T) lse[((long long)b * H + h) * T + q] = (m + log2f(l)) * LN2;
   }
+  if (EMIT) fp8_emit_amax(em, qseen, threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------ bf16 backward
-template <int HD, int NKF>
+// four gradient values of dqkv: bf16, and — EMIT — the fp8 byte copy at the same element offset (see attn_fwd_bf16)
+template <bool EMIT>
+__device__ __forceinline__ void st4_dqkv(bf16_t* dqkv, long long at, f4_t v, const Fp8Emit& em, float qs, float qmax, float& qseen) {
+  st4<bf16_t>(dqkv + at, v);
+  if (EMIT) *reinterpret_cast<unsigned*>(em.q + at) = fp8_pack4(round4<bf16_t>(v), qs, qmax, em.fmt, qseen);
+}
+template <int HD, int NKF, bool EMIT = false>
 __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                     bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale) {
+                                                     bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale, Fp8Emit em) {
   constexpr int TP = NKF * 16, KS = HD / 32, DF = HD / 16, IMG = TP * AttnLds<HD>::STRIDE;
   __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 2 * TP * 4];
   char* Qs = smem; char* Ks = smem + IMG; char* Vs = smem + 2 * IMG; char* Gs = smem + 3 * IMG;  // Gs = dO
@@ -212,6 +229,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  float qmax = 0.f, qseen = 0.f;
+  const float qs = EMIT ? fp8_emit_scale(em, lane, qmax) : 1.f;   // (EMIT: the fp8 copy of dqkv, see attn_fwd_bf16)
   const float c2 = scale * LOG2E;
   const int nblk = (T + 15) >> 4;
   // ---- pass 1: query rows -> dQ.  lane owns query column q; registers run over keys.
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
 #pragma unroll
       for (int s2 = 0; s2 < NKF / 2; ++s2) o = MFMA16(frag_cols_tr<HD>(Ks, 32 * s2, df * 16, t, g), fds[s2], o);
       int d = df * 16 + 4 * g;
-      if (q < T && d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, o);
+      if (q < T && d < hd) st4_dqkv<EMIT>(dqkv, (row0 + q) * ld + h * hd + d, o, em, qs, qmax, qseen);
     }
   }
   // ---- pass 2: key columns -> dK, dV.  lane owns key column; registers run over queries.
@@ -285,11 +304,12 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
       }
       int d = df * 16 + 4 * g;
       if (key < T && d < hd) {
-        st4<bf16_t>(dqkv + (row0 + key) * ld + D + h * hd + d, ok);
-        st4<bf16_t>(dqkv + (row0 + key) * ld + 2 * D + h * hd + d, ov);
+        st4_dqkv<EMIT>(dqkv, (row0 + key) * ld + D + h * hd + d, ok, em, qs, qmax, qseen);
+        st4_dqkv<EMIT>(dqkv, (row0 + key) * ld + 2 * D + h * hd + d, ov, em, qs, qmax, qseen);
       }
     }
   }
+  if (EMIT) fp8_emit_amax(em, qseen, lane);
 }
 
 // ------------------------------------------------------------------------------------------ bf16 backward, single pass
@@ -326,10 +346,10 @@ extern "C" int csmae_debug_attn_ts(unsigned long long* out) { return (int)hipMem
 #else
 #define TS(i)
 #endif
-template <int HD, int NKF>
+template <int HD, int NKF, bool EMIT = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                           bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale) {
+                                                           bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale, Fp8Emit em) {
   using L = AttnBwd1p<HD, NKF>;
   constexpr int TP = L::TP, NP = L::NP, KS = HD / 32, DF = HD / 16, IMG = L::IMG, QS = L::QS;
   __shared__ __attribute__((aligned(16))) char smem[L::LDS];
@@ -343,6 +363,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  float qmax = 0.f, qseen = 0.f;
+  const float qs = EMIT ? fp8_emit_scale(em, lane, qmax) : 1.f;   // (EMIT: the fp8 copy of dqkv, see attn_fwd_bf16)
   TS(0);
   HeadStager<HD, TP, 256, 2> sg;
   sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
@@ -478,8 +500,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
         for (int df = 0; df < DF; ++df) {
           const int d = df * 16 + 4 * g;
           if (key < T && d < hd) {
-            st4<bf16_t>(dqkv + (row0 + key) * ld + D + h * hd + d, dk[jj][df]);
-            st4<bf16_t>(dqkv + (row0 + key) * ld + 2 * D + h * hd + d, dv[jj][df]);
+            st4_dqkv<EMIT>(dqkv, (row0 + key) * ld + D + h * hd + d, dk[jj][df], em, qs, qmax, qseen);
+            st4_dqkv<EMIT>(dqkv, (row0 + key) * ld + 2 * D + h * hd + d, dv[jj][df], em, qs, qmax, qseen);
           }
         }
       }
@@ -488,8 +510,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   TS(10);
   for (int e = threadIdx.x; e < T * (HD / 4); e += blockDim.x) {
     const int q = e / (HD / 4), d = (e - q * (HD / 4)) * 4;
-    if (d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d));
+    if (d < hd) st4_dqkv<EMIT>(dqkv, (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d), em, qs, qmax, qseen);
   }
+  if (EMIT) fp8_emit_amax(em, qseen, lane);
 }
 
 // ---- the same pass with TWO key pairs per wave and a single sweep (NP <= 8 key pairs: every shape of the step).  The two-sweep form
@@ -497,10 +520,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
 // LDS and a workgroup barrier.  Here wave w owns key pairs w and w + 4 at once: one walk (NP steps and barriers), the Q / dO fragments
 // of a step (row and transposed forms) are read once for both key pairs, and the step's dQ contribution of 64 keys is summed in
 // registers before its single read-modify-write.
-template <int HD, int NKF>
+template <int HD, int NKF, bool EMIT = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                            bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale) {
+                                                            bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale, Fp8Emit em) {
   using L = AttnBwd1p<HD, NKF>;
   constexpr int TP = L::TP, NP = L::NP, KS = HD / 32, DF = HD / 16, IMG = L::IMG, QS = L::QS;
   static_assert(NP <= 8, "two key pairs per wave cover at most eight");
@@ -518,6 +541,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
   const long long row0 = (long long)b * T;
   const int ld = 3 * D;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = lane & 15, g = lane >> 4;
+  float qmax = 0.f, qseen = 0.f;
+  const float qs = EMIT ? fp8_emit_scale(em, lane, qmax) : 1.f;   // (EMIT: the fp8 copy of dqkv, see attn_fwd_bf16)
   TS(0);
   HeadStager<HD, TP, 256, 2> sg;
   sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
@@ -663,8 +688,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
       for (int df = 0; df < DF; ++df) {
         const int d = df * 16 + 4 * g;
         if (key < T && d < hd) {
-          st4<bf16_t>(dqkv + (row0 + key) * ld + D + h * hd + d, dk[pi][jj][df]);
-          st4<bf16_t>(dqkv + (row0 + key) * ld + 2 * D + h * hd + d, dv[pi][jj][df]);
+          st4_dqkv<EMIT>(dqkv, (row0 + key) * ld + D + h * hd + d, dk[pi][jj][df], em, qs, qmax, qseen);
+          st4_dqkv<EMIT>(dqkv, (row0 + key) * ld + 2 * D + h * hd + d, dv[pi][jj][df], em, qs, qmax, qseen);
         }
       }
     }
@@ -672,9 +697,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p2_bf16(const bf16_t* __restr
   TS(10);
   for (int e = threadIdx.x; e < T * (HD / 4); e += blockDim.x) {
     const int q = e / (HD / 4), d = (e - q * (HD / 4)) * 4;
-    if (d < hd) st4<bf16_t>(dqkv + (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d));
+    if (d < hd) st4_dqkv<EMIT>(dqkv, (row0 + q) * ld + h * hd + d, *reinterpret_cast<const f4_t*>(dqa + q * QS + d), em, qs, qmax, qseen);
   }
   TS(11);
+  if (EMIT) fp8_emit_amax(em, qseen, lane);
 }
 
 // ------------------------------------------------------------------------------------------ fp32 (parity mode)
@@ -894,22 +920,29 @@ static void launch_any(bool bwd, long long B, int Tn, int H, int D, int hd, floa
 
 // ------------------------------------------------------------------------------------------ dispatch
 template <int HD, int NKF>
-static void launch_fwd_bf16(int BH, const void* qkv, void* out, float* lse, int T, int H, int D, int hd, float scale, hipStream_t st) {
-  hipLaunchKernelGGL((attn_fwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, D, hd, scale);
+static void launch_fwd_bf16(int BH, const void* qkv, void* out, float* lse, int T, int H, int D, int hd, float scale, hipStream_t st, const Fp8Emit* em) {
+  if (em) hipLaunchKernelGGL((attn_fwd_bf16<HD, NKF, true>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, D, hd, scale, *em);
+  else hipLaunchKernelGGL((attn_fwd_bf16<HD, NKF, false>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, D, hd, scale, Fp8Emit{});
 }
 template <int HD, int NKF>
-static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int T, int H, int D, int hd, float scale, hipStream_t st) {
+static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int T, int H, int D, int hd, float scale, hipStream_t st,
+                            const Fp8Emit* em) {
   static const bool two_pass = getenv("CSMAE_ATTN_BWD_2PASS") != nullptr;  // tuning aid: the older two-pass kernel
   static const bool two_sweeps = getenv("CSMAE_ATTN_BWD_2SWEEP") != nullptr;  // tuning aid: one key pair per wave and sweep (the first single-pass version)
   constexpr bool KP2_OK = HD <= 32 && NKF >= 6 && NKF <= 16 && AttnBwd1p<HD, NKF>::LDS <= 160 * 1024;
-  if (KP2_OK && !two_pass && !two_sweeps)
-    CSMAE_LAUNCH((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
-  else if (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 && NKF >= 6 && !two_pass)  // (<= 64 tokens: fewer key pairs than waves, the two-pass split is faster)
-    CSMAE_LAUNCH((attn_bwd1p_bf16<HD, (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2)>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
-  else
-    CSMAE_LAUNCH((attn_bwd_bf16<HD, NKF>), dim3(BH), dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale);
+  constexpr int NK1 = AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2;
+#define ATTN_BWD_ARGS (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale
+  if (KP2_OK && !two_pass && !two_sweeps) {
+    if (em) CSMAE_LAUNCH((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2), true>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, *em);
+    else CSMAE_LAUNCH((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2), false>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, Fp8Emit{});
+  } else if (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 && NKF >= 6 && !two_pass) {  // (<= 64 tokens: fewer key pairs than waves, the two-pass split is faster)
+    if (em) CSMAE_LAUNCH((attn_bwd1p_bf16<HD, NK1, true>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, *em);
+    else CSMAE_LAUNCH((attn_bwd1p_bf16<HD, NK1, false>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, Fp8Emit{});
+  } else {
+    if (em) CSMAE_LAUNCH((attn_bwd_bf16<HD, NKF, true>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, *em);
+    else CSMAE_LAUNCH((attn_bwd_bf16<HD, NKF, false>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, Fp8Emit{});
+  }
+#undef ATTN_BWD_ARGS
 }
 
 // (head_dim bucket, key-fragment count) combinations whose LDS images fit 160 KiB in the backward kernel
@@ -930,7 +963,7 @@ static int check_common(const char* who, long long B, int T, int H, int D, int h
   return CSMAE_OK;
 }
 
-extern "C" int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* stream) {
+static int attn_fwd_impl(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* stream, const Fp8Emit* em) {
   const int D = H * hd;
   int rc = check_common("csmae_attn_fwd", B, T, H, D, hd);
   if (rc) return rc;
@@ -938,8 +971,8 @@ extern "C" int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, cons
   const float scale = 1.0f / sqrtf((float)hd);
   const int BH = (int)(B * H);
   if (dtype == CSMAE_BF16) {
-    if (!bf16_resident(T, hd)) { launch_any<bf16_t>(false, B, T, H, D, hd, scale, qkv, nullptr, nullptr, lse, nullptr, out, st); return csmae_check_launch("csmae_attn_fwd"); }
-#define CALLF(HDV, NK) launch_fwd_bf16<HDV, NK>(BH, qkv, out, lse, T, H, D, hd, scale, st)
+    if (!bf16_resident(T, hd)) { CSMAE_REQUIRE(!em, "csmae_attn_fwd_q: the fp8 copy is emitted by the LDS-resident kernels only (csmae_attn_resident)"); launch_any<bf16_t>(false, B, T, H, D, hd, scale, qkv, nullptr, nullptr, lse, nullptr, out, st); return csmae_check_launch("csmae_attn_fwd"); }
+#define CALLF(HDV, NK) launch_fwd_bf16<HDV, NK>(BH, qkv, out, lse, T, H, D, hd, scale, st, em)
     DISPATCH_BF16(CALLF)
 #undef CALLF
   } else if (dtype == CSMAE_F32) {
@@ -952,8 +985,27 @@ extern "C" int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, cons
   return csmae_check_launch("csmae_attn_fwd");
 }
 
-extern "C" int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
-                              const float* lse, void* dqkv, void* stream) {
+extern "C" int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* stream) {
+  return attn_fwd_impl(dtype, B, T, H, hd, qkv, out, lse, stream, nullptr);
+}
+// 1 when the (dtype, T, head_dim) shape runs the LDS-resident MFMA kernels, which can emit the fp8 copy of their output (csmae_attn_*_q)
+extern "C" int csmae_attn_resident(int dtype, int T, int hd) { return dtype == CSMAE_BF16 && bf16_resident(T, hd) ? 1 : 0; }
+static int attn_emit_check(const char* who, int dtype, int T, int hd, void* q, int fmt, const float* prev, float* next, float* dq) {
+  CSMAE_REQUIRE(dtype == CSMAE_BF16 && bf16_resident(T, hd), "%s: bf16 shapes of the LDS-resident kernels only (csmae_attn_resident)", who);
+  CSMAE_REQUIRE(q && prev && next && dq && (fmt == 0 || fmt == 1) && ((uintptr_t)q & 3) == 0, "%s: the fp8 copy needs q_out (4-byte aligned), amax_prev, amax_next, dq and fmt 0 / 1", who);
+  return CSMAE_OK;
+}
+// softmax(QK^T / sqrt d) V as csmae_attn_fwd, plus `q_out` [B*T, H*hd] = the output as OCP fp8 bytes (q_fmt 0: e4m3) scaled by FMAX / max(amax_prev[64]);
+// amax_next[64] receives partial maxima of |out|, dq[0] the de-quantisation factor (delayed scaling: csmae_gemm_fp8's conventions)
+extern "C" int csmae_attn_fwd_q(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* q_out, int q_fmt,
+                                const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream) {
+  if (int rc = attn_emit_check("csmae_attn_fwd_q", dtype, T, hd, q_out, q_fmt, q_amax_prev, q_amax_next, q_dq)) return rc;
+  const Fp8Emit em{(unsigned char*)q_out, q_amax_prev, q_amax_next, q_dq, q_fmt};
+  return attn_fwd_impl(dtype, B, T, H, hd, qkv, out, lse, stream, &em);
+}
+
+static int attn_bwd_impl(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
+                         const float* lse, void* dqkv, void* stream, const Fp8Emit* em) {
   const int D = H * hd;
   int rc = check_common("csmae_attn_bwd", B, T, H, D, hd);
   if (rc) return rc;
@@ -961,8 +1013,8 @@ extern "C" int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, cons
   const float scale = 1.0f / sqrtf((float)hd);
   const int BH = (int)(B * H);
   if (dtype == CSMAE_BF16) {
-    if (!bf16_resident(T, hd)) { launch_any<bf16_t>(true, B, T, H, D, hd, scale, qkv, out, dout, nullptr, lse, dqkv, st); return csmae_check_launch("csmae_attn_bwd"); }
-#define CALLB(HDV, NK) launch_bwd_bf16<HDV, NK>(BH, qkv, out, dout, lse, dqkv, T, H, D, hd, scale, st)
+    if (!bf16_resident(T, hd)) { CSMAE_REQUIRE(!em, "csmae_attn_bwd_q: the fp8 copy is emitted by the LDS-resident kernels only (csmae_attn_resident)"); launch_any<bf16_t>(true, B, T, H, D, hd, scale, qkv, out, dout, nullptr, lse, dqkv, st); return csmae_check_launch("csmae_attn_bwd"); }
+#define CALLB(HDV, NK) launch_bwd_bf16<HDV, NK>(BH, qkv, out, dout, lse, dqkv, T, H, D, hd, scale, st, em)
     DISPATCH_BF16(CALLB)
 #undef CALLB
   } else if (dtype == CSMAE_F32) {
@@ -980,4 +1032,15 @@ extern "C" int csmae_debug_attn_occupancy(int* fwd, int* bwd) {
   hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(fwd, attn_fwd_bf16<32, 14>, 256, 0);
   hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(bwd, attn_bwd_bf16<32, 14>, 256, 0);
   return (int)e1 * 1000 + (int)e2;
+}
+extern "C" int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
+                              const float* lse, void* dqkv, void* stream) {
+  return attn_bwd_impl(dtype, B, T, H, hd, qkv, out, dout, lse, dqkv, stream, nullptr);
+}
+// ... and its backward, plus `q_out` [B*T, 3*H*hd] = dqkv as fp8 bytes (q_fmt 1: e5m2), see csmae_attn_fwd_q
+extern "C" int csmae_attn_bwd_q(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout, const float* lse,
+                                void* dqkv, void* q_out, int q_fmt, const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream) {
+  if (int rc = attn_emit_check("csmae_attn_bwd_q", dtype, T, hd, q_out, q_fmt, q_amax_prev, q_amax_next, q_dq)) return rc;
+  const Fp8Emit em{(unsigned char*)q_out, q_amax_prev, q_amax_next, q_dq, q_fmt};
+  return attn_bwd_impl(dtype, B, T, H, hd, qkv, out, dout, lse, dqkv, stream, &em);
 }

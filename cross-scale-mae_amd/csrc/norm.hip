@@ -3,33 +3,6 @@
 // (wave-shuffle reductions, 16-B accesses), one workgroup per BatchNorm channel.
 #include "common.h"
 
-// fp8 mode, delayed scaling (csrc/fp8.hip, csmae_gemm_fp8): a kernel that produces a GEMM's A operand also writes it as fp8 bytes, scaled
-// with the amax the tensor had one step earlier (64 partial maxima), and records the new amax — no separate quantisation pass.
-struct Fp8Emit { unsigned char* q; const float* amax_prev; float* amax_next; float* dq; int fmt; };
-__device__ __forceinline__ float fp8_emit_scale(const Fp8Emit& e, int lane, float& qmax) {
-  qmax = e.fmt == 0 ? 448.0f : 57344.0f;
-  const float am = wave_max(e.amax_prev[lane & 63]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) e.dq[0] = am > 0.f ? am / qmax : 1.f;
-  return am > 0.f ? qmax / am : 1.f;
-}
-__device__ __forceinline__ unsigned fp8_pack4(f4_t v, float scale, float qmax, int fmt, float& seen) {
-  int p = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {   // non-finite values are not hidden: NaN passes through the clamp, NaN / Inf record an amax of +Inf (next step: scale 0 x Inf = NaN -> the loss gate trips)
-    const float a = fabsf(v[k]);
-    seen = fmaxf(seen, a == a ? a : INFINITY);
-    const float q = v[k] * scale;
-    v[k] = q != q ? q : fminf(fmaxf(q, -qmax), qmax);
-  }
-  if (fmt == 0) { p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true); }
-  else { p = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], p, true); }
-  return (unsigned)p;
-}
-__device__ __forceinline__ void fp8_emit_amax(const Fp8Emit& e, float seen, int lane) {
-  seen = wave_max(seen);
-  if (lane == 0 && seen > 0.f) atomicMax(reinterpret_cast<unsigned*>(e.amax_next) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(seen));
-}
-
 // ------------------------------------------------------------------------------------------ LayerNorm forward
 template <typename TX, typename TO, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const TX* __restrict__ x, const float* __restrict__ gamma,

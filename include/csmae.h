@@ -111,6 +111,16 @@ int csmae_gemm_force_tile(int cfg);
 int csmae_attn_fwd(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* stream);
 int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
                    const float* lse, void* dqkv, void* stream);
+/* fp8 mode (BASELINE configs[4]): the same two kernels also leave their output as OCP fp8 bytes for the nn.Linear that consumes it —
+ * attn.proj forward reads `out` (q_fmt 0: e4m3), attn.qkv's backward reads dqkv (q_fmt 1: e5m2) — quantised from the rounded bf16 values
+ * with FMAX / max(q_amax_prev[64]) (the tensor's amax one step earlier: delayed scaling, conventions of csmae_gemm_fp8); q_amax_next[64]
+ * receives partial maxima of |x|, q_dq[0] the de-quantisation factor.  bf16 shapes of the LDS-resident kernels only: csmae_attn_resident().
+ * Same reference expression (timm Attention inside Block, models_mae/MAE_ViT_Baseline.py:160-188); replaces a csmae_fp8_quantize pass. */
+int csmae_attn_resident(int dtype, int T, int hd);
+int csmae_attn_fwd_q(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* q_out, int q_fmt,
+                     const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream);
+int csmae_attn_bwd_q(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout, const float* lse,
+                     void* dqkv, void* q_out, int q_fmt, const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream);
 
 /* ---- nn.LayerNorm(eps=1e-6) (MAE_ViT_Baseline.py:43-45): x [M,D] in x_dtype (the residual stream: fp32, or bf16 in throughput
  * mode); y in out_dtype (+ optional fp32 copy y32); statistics in fp32.

@@ -347,6 +347,39 @@ def test_launch_carried_event_orders_a_second_stream(ops, case):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("geom", [(4, 197, 16, 32), (3, 65, 16, 80), (2, 257, 16, 32), (5, 50, 12, 64)])
+def test_attention_emits_the_fp8_copies_of_a_separate_quantisation_pass(ops, geom):
+    """csmae_attn_fwd_q / csmae_attn_bwd_q (fp8 mode, BASELINE configs[4]): the kernels' fp8 copies of `out` (e4m3, for attn.proj) and dqkv (e5m2,
+    for attn.qkv's backward) are the bytes csmae_fp8_quantize makes from the bf16 tensors with the same previous-step amax; the recorded amax
+    is the tensor's; the bf16 outputs are the plain kernels'."""
+    B, T, H, hd = geom
+    D = H * hd
+    assert ops.attn_resident(ops.BF16, T, hd)
+    qkv = dev(rnd(B * T, 3 * D, seed=50).to(torch.bfloat16))
+    dout = dev(rnd(B * T, D, seed=51).to(torch.bfloat16))
+    out0 = torch.empty(B * T, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, T, device="cuda")
+    dq0 = torch.empty(B * T, 3 * D, device="cuda", dtype=torch.bfloat16)
+    ops.attn_fwd(qkv, out0, lse, B, T, H, hd)
+    ops.attn_bwd(qkv, out0, dout, lse, dq0, B, T, H, hd)
+    for which, ref, fmt in (("fwd", out0, ops.FP8_E4M3), ("bwd", dq0, ops.FP8_E5M2)):
+        prev = torch.zeros(ops.FP8_SLOTS, device="cuda")
+        prev[7] = float(ref.float().abs().max()) * 0.8      # a stale amax: some values clamp, as one step after a jump
+        nxt, dq = torch.zeros(ops.FP8_SLOTS, device="cuda"), torch.zeros(1, device="cuda")
+        q = torch.zeros(ref.shape, device="cuda", dtype=torch.uint8)
+        got = torch.zeros_like(ref)
+        if which == "fwd":
+            ops.attn_fwd(qkv, got, lse, B, T, H, hd, emit=(q, fmt, prev, nxt, dq))
+        else:
+            ops.attn_bwd(qkv, out0, dout, lse, got, B, T, H, hd, emit=(q, fmt, prev, nxt, dq))
+        assert torch.equal(got, ref), which
+        want_q, want_next, want_dq = torch.zeros_like(q), torch.zeros(ops.FP8_SLOTS, device="cuda"), torch.zeros(1, device="cuda")
+        ops.fp8_quantize(ref, want_q, prev, want_dq, fmt=fmt, amax_next=want_next)
+        assert torch.equal(q, want_q), which
+        assert float(nxt.max()) == float(ref.float().abs().max()) == float(want_next.max()), which
+        assert float(dq) == float(want_dq), which
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("MD", [(37, 768), (200, 512), (9, 64), (5, 128), (16, 1024), (7, 1280)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
