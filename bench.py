@@ -154,6 +154,12 @@ def main():
     torch.manual_seed(0 + rank)  # main_pretrain.py:368
     samples = torch.randn(a.batch, chans, size, size, device=device)
 
+    main_cus = os.environ.get("CSMAE_MAIN_CUS")   # experiment aid (CU partition): "lo:hi" = mask bits of the main stream
+    if main_cus:
+        from csmae_hip import ops as _ops
+        lo, hi = (int(v) for v in main_cus.split(":"))
+        torch.cuda.set_stream(_ops.cu_masked_stream(lo, hi))
+
     def step():
         opt.zero_grad(set_to_none=True)
         loss, _, _ = wrapped(samples, mask_ratio=0.75)

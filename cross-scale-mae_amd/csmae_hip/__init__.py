@@ -12,6 +12,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 import torch  # noqa: F401  -- must come first: libcsmae_hip.so has to bind to the HIP runtime PyTorch already loaded (one runtime per process)
 
 F32, BF16 = 0, 1
+ABI_VERSION = 5
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
 LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4, "none": 5}
 # the ssim family: kind -> (per-patch kind, pyramid levels, weight of the ssim term)  MAE_ViT_Shared.py:165-267
@@ -52,6 +53,7 @@ _SIGNATURES = {
     "csmae_unshuffle_bwd": [I, I, L, I, I, I, P, P, P, P, P],
     "csmae_rows_gather": [I, L, I, P, L, L, L, P, P],
     "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],
+    "csmae_rows_gather_idx": [L, I, I, I, P, P, L, P, P],
     "csmae_target_minmax": [I, L, I, I, I, I, P, P, P, P, P],
     "csmae_recon_loss_fwd": [I, I, L, I, I, I, I, P, P, P, L, P, P, P],
     "csmae_recon_loss_bwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P, F, P, P, L, P],
@@ -74,6 +76,8 @@ _SIGNATURES = {
     "csmae_cast_f32_to_bf16": [L, P, P, P],
     "csmae_cast_bf16_to_f32": [L, P, P, P],
     "csmae_colsum": [I, L, I, P, L, P, P],
+    "csmae_stream_create_cu_mask": [I, P, P],
+    "csmae_stream_destroy": [P],
 }
 
 _lib = None
@@ -99,7 +103,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = sig
         fn.restype = c_int
-    if lib.csmae_abi_version() != 4:
+    if lib.csmae_abi_version() != ABI_VERSION:
         raise CsmaeError("libcsmae_hip ABI version mismatch")
     _lib = lib
     return lib

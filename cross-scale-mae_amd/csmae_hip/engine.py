@@ -527,6 +527,15 @@ class Engine:
         self._ev_i += 1
         return self._events[self._ev_i - 1]
 
+    def _new_side(self):
+        """The weight-gradient stream.  CSMAE_DW_CUS=n confines it to n compute units of every XCD (ops.cu_masked_stream) instead of letting its
+        160-workgroup launches time-slice whole CUs with the main chain; the forward's second-view stream is then a stream of its own."""
+        n = int(os.environ.get("CSMAE_DW_CUS", "0"))
+        if n <= 0:
+            return torch.cuda.Stream()
+        self._side_masked = True
+        return ops.cu_masked_stream(0, 8 * n)
+
     def _join_side(self):
         self.main.wait_stream(self.side)
         self._side_reads.clear()
@@ -680,7 +689,9 @@ class Engine:
             ops.ln_param_reduce(hi - lo, M, Dm, part[lo:hi], goff[lo:hi], self.flat.g, st=self.st)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool):
+    def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool,
+                img1: Optional[torch.Tensor] = None):
+        """`img1`: the second view given explicitly (MAE_ViT_MsLd_PAIRED, MAE_ViT_MsLd.py:79-146) instead of the random resized crop of `imgs`."""
         c = self.cfg
         N = imgs.shape[0]
         keep = int(c["L"] * (1 - mask_ratio))
@@ -697,8 +708,9 @@ class Engine:
         self._refresh_fold()
         self._fp8_begin()
         img0 = imgs
-        img1 = None
-        if self.views == 2:
+        if self.views != 2:
+            img1 = None
+        elif img1 is None:
             ws.box.copy_(box_host, non_blocking=True)
             ops.crop_resize(img0, ws.imgs_crop, ws.box, st=st)
             img1 = ws.imgs_crop
@@ -713,7 +725,7 @@ class Engine:
         main = torch.cuda.current_stream()
         two = self.views == 2 and ops._timer is None and not os.environ.get("CSMAE_FWD_ONE_STREAM")
         if self.side is None:
-            self.side = torch.cuda.Stream()
+            self.side = self._new_side()
         if self.aux is None:
             self.aux = torch.cuda.Stream()
         ce_done = None
@@ -758,7 +770,7 @@ class Engine:
             if nch < 2 or B2 % nch:
                 nch = 2
             while len(self._fwd_streams) < nch - 1:
-                self._fwd_streams.append(self.side if not self._fwd_streams else torch.cuda.Stream())
+                self._fwd_streams.append(self.side if (not self._fwd_streams and not getattr(self, "_side_masked", False)) else torch.cuda.Stream())
             per = B2 // nch
             # the main stream starts first (the other ones wait for the stem) and would idle at the join: it takes `_fwd_lead` samples more
             # than its share (chunks are sample ranges: attention, LayerNorm and the GEMM rows do not care where a view ends)
@@ -909,6 +921,19 @@ class Engine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, gout: torch.Tensor, accumulate: bool, gen: Optional[int] = None):
+        """Engine._backward, optionally with the main chain confined to a CU range for the length of the reverse pass (experiment aid,
+        DESIGN §5 "CU partition": CSMAE_BWD_MAIN_CUS=lo:hi mask bits; the forward pass keeps the whole chip)."""
+        rng = os.environ.get("CSMAE_BWD_MAIN_CUS")
+        if not rng:
+            return self._backward(gout, accumulate, gen)
+        lo, hi = (int(v) for v in rng.split(":"))
+        outer, inner = torch.cuda.current_stream(), ops.cu_masked_stream(lo, hi)
+        inner.wait_stream(outer)
+        with torch.cuda.stream(inner):
+            self._backward(gout, accumulate, gen)
+        outer.wait_stream(inner)
+
+    def _backward(self, gout: torch.Tensor, accumulate: bool, gen: Optional[int] = None):
         """Reverse pass of the LAST forward (the activations live in the engine's one workspace).  `gen` = the forward this call
         belongs to (the autograd node passes it): a forward that has been overwritten by a later one, or whose backward already ran,
         raises instead of silently differentiating somebody else's activations."""
@@ -929,7 +954,7 @@ class Engine:
         B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
         self.main = torch.cuda.current_stream()
         if self.side is None:
-            self.side = torch.cuda.Stream()
+            self.side = self._new_side()
         self._ev_i, self._tog = 0, 0
         self._side_reads.clear()
         zeroed = None
@@ -1029,4 +1054,9 @@ class Engine:
         for name, p in self.flat.params.items():
             if p.requires_grad and not name.startswith("encoder_norm."):
                 p.grad = self.flat.grad_views[name]
+            elif not (name in _FROZEN or name.startswith("encoder_norm.")):
+                # a parameter the USER froze: the kernels write dW / db of every layer whether or not its Parameter takes part, so its slot is
+                # cleared here (behind the last writer and the all-reduce on this stream) — the flat buffer then holds exactly what torch's
+                # `.grad`s would, and global-norm clipping can norm it as a whole (util.misc.clip_grad_norm_; util/misc.py:310-318)
+                self.flat.grad_views[name].zero_()
 

@@ -64,6 +64,26 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_masked = {}
+
+
+def cu_masked_stream(lo: int, hi: int, total_cus: int = 256):
+    """A torch stream whose kernels run only on the compute units of mask bits [lo, hi) (csmae_stream_create_cu_mask: bit i is CU i / 8 of
+    XCD i % 8, so a range whose ends are multiples of 8 is the same CUs in every XCD).  Cached per range: queues are a finite resource."""
+    key = (lo, hi, total_cus, torch.cuda.current_device())
+    s = _masked.get(key)
+    if s is None:
+        if not (0 <= lo < hi <= total_cus):
+            raise ValueError(f"cu_masked_stream: empty or out-of-range CU range [{lo}, {hi}) of {total_cus}")
+        words = (total_cus + 31) // 32
+        bits = ((1 << (hi - lo)) - 1) << lo
+        mask = (ctypes.c_uint32 * words)(*[(bits >> (32 * w)) & 0xFFFFFFFF for w in range(words)])
+        h = ctypes.c_void_p()
+        check(load().csmae_stream_create_cu_mask(words, ctypes.cast(mask, ctypes.c_void_p), ctypes.cast(ctypes.byref(h), ctypes.c_void_p)), "csmae_stream_create_cu_mask")
+        s = _masked[key] = torch.cuda.ExternalStream(h.value)
+    return s
+
+
 class launch_done:
     """`with launch_done(ev, st): <one op>` — the op's kernel carries the torch event `ev` as its own completion signal (csmae_next_launch_event)
     instead of a marker packet recorded behind it on stream `st`; ops whose launch site does not support that get the plain record.  `ev` must
@@ -333,6 +353,15 @@ def unshuffle_bwd(dxd, ids_restore, dz, dmask_token, B2, L, keep, st=None):
 def rows_gather(src, dst, group, gstride, off, st=None):
     check(load().csmae_rows_gather(dt(dst), dst.shape[0], dst.shape[1], _p(src), group, gstride, off, _p(dst), st if st is not None else stream()),
           "csmae_rows_gather")
+
+
+def rows_gather_idx(x, ids, keep, out, st=None):
+    """out[n, k, :] = x[n, ids[n, k], :] for k < keep (x [N, L, D] fp32, ids [N, >= keep] int32, out [N, keep, D] fp32)."""
+    N, L, D = x.shape
+    assert x.dtype == out.dtype == torch.float32 and ids.dtype == torch.int32 and x.is_contiguous() and out.is_contiguous() and ids.stride(1) == 1
+    assert out.shape == (N, keep, D) and ids.shape[0] == N and ids.shape[1] >= keep
+    check(load().csmae_rows_gather_idx(N, L, keep, D, _p(x), _p(ids), ids.stride(0), _p(out), st if st is not None else stream()), "csmae_rows_gather_idx")
+    return out
 
 
 def rows_scatter_add(src, dst, group, gstride, off, scale=1.0, st=None):

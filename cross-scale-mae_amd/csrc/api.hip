@@ -21,7 +21,7 @@ int csmae_check_launch(const char* what) {
 }
 
 extern "C" const char* csmae_last_error(void) { return g_err; }
-extern "C" int csmae_abi_version(void) { return 4; }
+extern "C" int csmae_abi_version(void) { return 5; }
 
 // ---- an event attached to the next launch (common.h: CSMAE_LAUNCH).  The reference has no counterpart: torch records events behind kernels
 // (autograd's stream hand-offs, DDP's bucket hooks — main_pretrain.py:417-421); here the weight-gradient stream of csmae_hip/engine.py waits for
@@ -35,6 +35,25 @@ extern "C" int csmae_flush_launch_event(void* stream) {
   g_csmae_launch_event = nullptr;
   hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
   if (e != hipSuccess) { csmae_set_error("csmae_flush_launch_event: %s", hipGetErrorString(e)); return CSMAE_ERR_LAUNCH; }
+  return CSMAE_OK;
+}
+// ---- a HIP stream confined to a subset of the compute units (include/csmae.h).  The reference's counterpart is the CUDA stream DDP's reducer and
+// autograd's hand-offs run on (main_pretrain.py:417-421) — which cannot be confined; here the weight-gradient stream (and RCCL's) gets a fixed
+// share of the CUs instead of time-slicing whole CUs away from the main chain's kernels.
+extern "C" int csmae_stream_create_cu_mask(int words, const unsigned* mask, void** out) {
+  CSMAE_REQUIRE(words > 0 && mask && out, "csmae_stream_create_cu_mask: bad args");
+  int any = 0;
+  for (int i = 0; i < words; ++i) any |= mask[i] != 0u;
+  CSMAE_REQUIRE(any, "csmae_stream_create_cu_mask: empty mask (a queue without compute units never finishes)");
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+  if (e != hipSuccess) { csmae_set_error("csmae_stream_create_cu_mask: %s", hipGetErrorString(e)); return CSMAE_ERR_LAUNCH; }
+  *out = (void*)st;
+  return CSMAE_OK;
+}
+extern "C" int csmae_stream_destroy(void* stream) {
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) { csmae_set_error("csmae_stream_destroy: %s", hipGetErrorString(e)); return CSMAE_ERR_LAUNCH; }
   return CSMAE_OK;
 }
 #ifndef CSMAE_SRC_HASH

@@ -1027,12 +1027,6 @@ static int attn_bwd_impl(int dtype, long long B, int T, int H, int hd, const voi
   return csmae_check_launch("csmae_attn_bwd");
 }
 
-// tuning aid (not in include/csmae.h): resident workgroups per CU the runtime computes for the two decoder-shape kernels
-extern "C" int csmae_debug_attn_occupancy(int* fwd, int* bwd) {
-  hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(fwd, attn_fwd_bf16<32, 14>, 256, 0);
-  hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(bwd, attn_bwd_bf16<32, 14>, 256, 0);
-  return (int)e1 * 1000 + (int)e2;
-}
 extern "C" int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv, const void* out, const void* dout,
                               const float* lse, void* dqkv, void* stream) {
   return attn_bwd_impl(dtype, B, T, H, hd, qkv, out, dout, lse, dqkv, stream, nullptr);

@@ -354,6 +354,24 @@ extern "C" int csmae_rows_scatter_add(int dtype, long long rows, int D, const vo
   return csmae_check_launch("csmae_rows_scatter_add");
 }
 
+// out[n, k, :] = x[n, ids[n, k], :]  — the row gather of the stand-alone `random_masking` (MAE_ViT_Shared.py:77: torch.gather over ids_keep)
+__global__ __launch_bounds__(128) void rows_gather_idx_kernel(long long rows, int keep, int L, int D, const float* __restrict__ x, const int* __restrict__ ids,
+                                                              long long ids_ld, float* __restrict__ out) {
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long long n = r / keep; const int k = (int)(r - n * keep);
+    const float* s = x + (n * L + ids[n * ids_ld + k]) * (long long)D;
+    float* d = out + r * (long long)D;
+    if ((D & 3) == 0) { for (int c = threadIdx.x; c < (D >> 2); c += blockDim.x) *reinterpret_cast<f4_t*>(d + c * 4) = *reinterpret_cast<const f4_t*>(s + c * 4); }
+    else for (int c = threadIdx.x; c < D; c += blockDim.x) d[c] = s[c];
+  }
+}
+extern "C" int csmae_rows_gather_idx(long long N, int L, int keep, int D, const float* x, const int* ids, long long ids_ld, float* out, void* stream) {
+  CSMAE_REQUIRE(N > 0 && L > 0 && keep > 0 && keep <= L && D > 0 && ids_ld >= keep, "csmae_rows_gather_idx: bad geometry N=%lld L=%d keep=%d D=%d", N, L, keep, D);
+  const long long rows = N * keep;
+  hipLaunchKernelGGL(rows_gather_idx_kernel, dim3((unsigned)fmin((double)rows, 8192.0)), dim3(128), 0, (hipStream_t)stream, rows, keep, L, D, x, ids, ids_ld, out);
+  return csmae_check_launch("csmae_rows_gather_idx");
+}
+
 // ------------------------------------------------------------------------------------------ input step
 // The reference's training transform (util/datasets.py:120-136) on the GPU, one kernel per batch of decoded uint8 images:
 //   ToTensor (u8 / 255) -> Normalize(mean, std) -> RandomHorizontalFlip -> RandomVerticalFlip ->

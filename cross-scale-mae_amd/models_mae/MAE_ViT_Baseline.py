@@ -18,8 +18,8 @@ class _StepFn(torch.autograd.Function):
     (device guards only, no work) after every backward — 0.7 ms per step with the GPU idle behind it."""
 
     @staticmethod
-    def forward(ctx, model, engine, imgs, mask_ratio, noise, box, anchor):
-        ws = engine.forward(imgs, mask_ratio, noise, box, model.training)
+    def forward(ctx, model, engine, imgs, mask_ratio, noise, box, anchor, img1=None):
+        ws = engine.forward(imgs, mask_ratio, noise, box, model.training, img1=img1)
         ctx.model, ctx.engine, ctx.gen = model, engine, engine.gen
         ctx.set_materialize_grads(False)
         outs = model._outputs(engine, ws, imgs.shape[0])
@@ -34,7 +34,7 @@ class _StepFn(torch.autograd.Function):
             model = ctx.model
             grads = [p.grad for p in model.parameters() if p.requires_grad]
             ctx.engine.backward(gloss, accumulate=any(g is not None for g in grads), gen=ctx.gen)
-        return (None,) * 7
+        return (None,) * 8
 
 
 def _check_ssim_geometry(C):
@@ -166,7 +166,11 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
         emb = ws.emb32.view(ws.B2, ws.Td, c["Dd"])
         return (ws.losses[0].clone(), pred[:N, 1:, :], ws.mask[:N], lat[:N], emb[:N])
 
-    def _run(self, imgs, mask_ratio, noise, box):
+    def _run(self, imgs, mask_ratio, noise, box, img1=None):
+        if img1 is not None:
+            if img1.shape != imgs.shape or img1.device != imgs.device:
+                raise AssertionError(f"the two views must have the same shape and device: {tuple(imgs.shape)} vs {tuple(img1.shape)}")
+            img1 = img1.contiguous().float()
         if imgs.dim() != 4 or imgs.shape[1] != self.input_channels or imgs.shape[2] != self.input_size or imgs.shape[3] != self.input_size:
             raise AssertionError(f"input {tuple(imgs.shape)} does not match (N, {self.input_channels}, {self.input_size}, {self.input_size})")
         imgs = imgs.contiguous().float()
@@ -175,8 +179,8 @@ class MAE_ViT_Baseline(MAE_ViT_Shared):
             anchor = self.__dict__.get("_anchor")
             if anchor is None or anchor.device != imgs.device:
                 anchor = self.__dict__["_anchor"] = torch.zeros((), device=imgs.device, requires_grad=True)
-            return _StepFn.apply(self, eng, imgs, mask_ratio, noise, box, anchor)
-        ws = eng.forward(imgs, mask_ratio, noise, box, self.training)
+            return _StepFn.apply(self, eng, imgs, mask_ratio, noise, box, anchor, img1)
+        ws = eng.forward(imgs, mask_ratio, noise, box, self.training, img1=img1)
         # Outside the training fast path the outputs are fresh tensors, as in the reference.  Under autograd (the path above) the
         # prediction / latents / embeddings are VIEWS of the engine's activation workspace: valid until the model's next forward,
         # which overwrites them — clone what must outlive it (the loss is always a fresh scalar).

@@ -70,3 +70,39 @@ class MAE_ViT_MsLd(MAE_ViT_Baseline):
 
     def forward(self, imgs, mask_ratio=0.75, mask_seed: int = None, return_embeds=False, consistent_mask=False):
         return self._forward_ms(imgs, mask_ratio, mask_seed, return_embeds, consistent_mask)
+
+
+class MAE_ViT_MsLd_PAIRED(MAE_ViT_Baseline):
+    """Two explicit views instead of the random crop (reference MAE_ViT_MsLd.py:79-146): `forward(imgs1, imgs2, ...)`, the same summed (or
+    averaged) reconstruction loss; returns the first view's prediction and mask.  No `crop` child (commented out in the reference), so the
+    module tree and `state_dict` are MAE_ViT_Baseline's."""
+
+    VARIANT = "MsLd"
+
+    def __init__(self, ms_range=(0.2, 0.8), ms_decoder_loss_reduction: str = "sum", **kwargs):
+        super().__init__(**kwargs)
+        self.ms_decoder_loss_reduction = ms_decoder_loss_reduction.lower()
+        self.allowed_reductions = ["mean", "sum"]
+        assert self.ms_decoder_loss_reduction in self.allowed_reductions, f"ms_decoder_loss_reduction must be one of: {self.allowed_reductions}"
+
+    _outputs = MAE_ViT_MsLd._outputs
+
+    def _draw(self, imgs, mask_ratio, mask_seed, consistent_mask=False):
+        """Draw order of the reference (MAE_ViT_MsLd.py:119-133): [seed] -> [seed] rand(N,L) -> [seed] rand(N,L); no crop box."""
+        N, L = imgs.shape[0], self.num_patches
+        hook, self._test_draws = self._test_draws, None
+        if mask_seed is not None:
+            torch.manual_seed(mask_seed)
+        elif consistent_mask:
+            mask_seed = torch.randint(0, 2 ** 32 - 1, (1,)).item()
+        noises = []
+        for v in range(2):
+            if mask_seed is not None:
+                torch.manual_seed(mask_seed)
+            noises.append(hook["noise"][v].to(imgs.device) if hook else torch.rand(N, L, device=imgs.device))
+        return torch.cat(noises, dim=0), None
+
+    def forward(self, imgs1, imgs2, mask_ratio=0.75, mask_seed: int = None, return_embeds=False, consistent_mask=False):
+        noise, _ = self._draw(imgs1, mask_ratio, mask_seed, consistent_mask)
+        loss, pred, mask, eo, ec, do, dc = self._run(imgs1, mask_ratio, noise, None, img1=imgs2)
+        return (loss, pred, mask) if not return_embeds else (loss, pred, mask, (eo, ec), (do, dc))

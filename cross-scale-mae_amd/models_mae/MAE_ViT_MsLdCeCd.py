@@ -1,6 +1,6 @@
 """Headline model: MsLd + cross-decoder predictor loss + encoder NT-Xent contrastive loss
 (reference models_mae/MAE_ViT_MsLdCeCd.py:7-84; tau = 0.5, cosine similarity, per-GPU negatives)."""
-from .MAE_ViT_MsLd import MAE_ViT_MsLd
+from .MAE_ViT_MsLd import MAE_ViT_MsLd, MAE_ViT_MsLd_PAIRED  # noqa: F401  (the reference imports both here, MAE_ViT_MsLdCeCd.py:2)
 from .MAE_ViT_Shared import check_loss
 from .MLP import MLP
 

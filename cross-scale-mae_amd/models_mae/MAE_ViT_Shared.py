@@ -40,8 +40,8 @@ class MAE_ViT_Shared(nn.Module):
         return x.reshape(x.shape[0], g, g, p, p, c).permute(0, 5, 1, 3, 2, 4).reshape(x.shape[0], c, g * p, g * p)
 
     def random_masking(self, x, mask_ratio):
-        """MAE_ViT_Shared.py:57-84.  Indices come from the HIP rank-sort (stable ascending == argsort on tie-free rows);
-        the row gather of this stand-alone helper is a torch index op (inside the step it is fused into patch_gather)."""
+        """MAE_ViT_Shared.py:57-84.  Indices come from the HIP rank-sort (stable ascending == argsort on tie-free rows), the kept rows
+        from a HIP row gather (inside the step both are fused into patch_gather)."""
         from csmae_hip import ops
         N, L, D = x.shape
         keep = int(L * (1 - mask_ratio))
@@ -50,8 +50,11 @@ class MAE_ViT_Shared(nn.Module):
         mask = torch.empty(N, L, device=x.device)
         ids_keep = torch.empty(N, max(keep, 1), device=x.device, dtype=torch.int32)
         ops.mask_sort(noise, keep, ids_restore, mask, ids_keep)
-        x_masked = torch.gather(x, 1, ids_keep[:, :keep].long().unsqueeze(-1).expand(-1, -1, D))
-        return x_masked, mask, ids_restore
+        if keep < 1:
+            return x.new_empty(N, 0, D), mask, ids_restore
+        x32 = x.contiguous().float()
+        x_masked = ops.rows_gather_idx(x32, ids_keep, keep, torch.empty(N, keep, D, device=x.device, dtype=torch.float32))
+        return x_masked.to(x.dtype), mask, ids_restore
 
     def scale_01(self, x):
         return (x - x.min()) / (x.max() - x.min() + 1.0e-6)

@@ -5,7 +5,7 @@ works — main_pretrain.py:398), presets and `state_dict` keys as the reference'
 The reference's `*_cross*` / `*shunted*` factories reference modules that were never committed (`__init__.py:16-19`) and are
 omitted.  `mae_vit_{large,huge}_MsLdCeCd` are build-side additions for BASELINE.json configs 3-5."""
 from .MAE_ViT_Baseline import MAE_ViT_Baseline
-from .MAE_ViT_MsLd import MAE_ViT_MsLd
+from .MAE_ViT_MsLd import MAE_ViT_MsLd, MAE_ViT_MsLd_PAIRED
 from .MAE_ViT_MsLdCd import MAE_ViT_MsLdCd
 from .MAE_ViT_MsLdCe import MAE_ViT_MsLdCe
 from .MAE_ViT_MsLdCeCd import MAE_ViT_MsLdCeCd

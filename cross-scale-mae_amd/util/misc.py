@@ -195,8 +195,9 @@ def clip_grad_norm_(parameters, max_norm):
     """`torch.nn.utils.clip_grad_norm_(parameters, max_norm)` (util/misc.py:314-316; `max_norm=None`: `get_grad_norm_`, :318) -> the total
     2-norm as a 0-dim tensor, gradients scaled in place by min(1, max_norm / (norm + 1e-6)).  When the gradients are the engine's
     views of the flat gradient buffer — the case on the MI355X path — this is two streaming HIP kernels over that one buffer with the
-    coefficient read from device memory (no host sync, no ~250-tensor foreach); anything else (a foreign model, CPU tests of the
-    loop) goes through torch."""
+    coefficient read from device memory (no host sync, no ~250-tensor foreach), also when the user has frozen some parameters (their
+    slots are cleared by the engine); anything else (a foreign model, a subset of the model's parameters, CPU tests of the loop) goes
+    through torch."""
     if isinstance(parameters, torch.Tensor):
         parameters = [parameters]
     params = [p for p in parameters if p.grad is not None]
@@ -215,13 +216,8 @@ def clip_grad_norm_(parameters, max_norm):
             # every parameter of the model that has a gradient must be in the call (the buffer is normed as a whole)
             if flat is not None and views != sum(1 for q in flat.params.values() if q.grad is not None):
                 flat = None
-            # The buffer is normed as a whole, and the engine writes dW / db of every layer whether or not its Parameter is frozen (it only
-            # declines to hand the view to `.grad`): with a user-frozen parameter the flat norm would include gradients that
-            # torch.nn.utils.clip_grad_norm_ — and the reference — leave out.  Slots that are never written (the sin-cos tables, the
-            # discarded encoder_norm) hold zeros and are harmless.
-            if flat is not None and any(not q.requires_grad and not (n.endswith("pos_embed") or n.startswith("encoder_norm."))
-                                        for n, q in flat.params.items()):
-                flat = None
+            # (the buffer is normed as a whole: slots of parameters without a gradient hold zeros — never written (sin-cos tables, the
+            # discarded encoder_norm) or cleared at the end of Engine.backward (parameters the user froze))
     if flat is None:
         if max_norm is None:
             return get_grad_norm_(params)

@@ -172,6 +172,9 @@ int csmae_rows_gather(int dtype, long long rows, int D, const float* src, long l
                       void* dst, void* stream);
 int csmae_rows_scatter_add(int dtype, long long rows, int D, const void* src, float scale, long long group, long long gstride,
                            long long off, float* dst, void* stream);
+/* MAE_ViT_Shared.py:77 (`torch.gather(x, dim=1, index=ids_keep.unsqueeze(-1).repeat(1, 1, D))` of the stand-alone random_masking):
+ * out[n, k, :] = x[n, ids[n * ids_ld + k], :], x [N, L, D] fp32, ids int32 (csmae_mask_sort's ids_keep), out [N, keep, D] fp32. */
+int csmae_rows_gather_idx(long long N, int L, int keep, int D, const float* x, const int* ids, long long ids_ld, float* out, void* stream);
 
 /* ---- MAE_ViT_Shared.forward_loss (:269-290) with process_target/patchify fused (:24-39,97-111).
  * pred is [B2*(L+1), ldp] (row 0 of every sample = cls, ignored); rowloss [B2*L]. */
@@ -237,6 +240,16 @@ int csmae_clip_grad_norm(long long n, float* g, float max_norm, float* scratch, 
 int csmae_cast_f32_to_bf16(long long n, const float* src, void* dst, void* stream);
 int csmae_cast_bf16_to_f32(long long n, const void* src, float* dst, void* stream);
 int csmae_colsum(int dtype, long long M, int N, const void* x, long long ld, float* out, void* stream);
+
+
+/* ---- a stream confined to a subset of the compute units (ABI version 5).  The reference overlaps DDP's bucket all-reduces and autograd's
+ * weight-gradient work with the main chain on CUDA streams that share every SM (main_pretrain.py:417-421); on MI355X a GEMM workgroup owns a
+ * whole CU (160 KiB of LDS, 512 threads), so two streams time-slice CUs unless each is given its own.  `mask`: `words` x 32 bits; on this
+ * 8-XCD part bit i is CU (i / 8) of XCD (i % 8) (the driver deals the bits round-robin over XCDs, then over shader engines), so the
+ * first 8 n bits are n CUs of every XCD.  `*out` receives a hipStream_t (wrap it with torch.cuda.ExternalStream); destroy it with
+ * csmae_stream_destroy once no work is pending on it. */
+int csmae_stream_create_cu_mask(int words, const unsigned* mask, void** out);
+int csmae_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -345,11 +345,12 @@ def predictor(sd, x: Tensor, bn: Optional[dict] = None, training: bool = True, m
 
 
 # --------------------- models_mae/MAE_ViT_MsLd.py:37-77 + MsLd{Le,Cd,LeCd,CeCd}.py forward bodies
-def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=None, training=True):
+def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=None, training=True, second=None):
     """Two-view forward with every loss term of the `variant` in cfg.  RNG is external: the caller
-    supplies the crop box and both noise tensors (reference draw order: box, rand(N,L), rand(N,L))."""
+    supplies the crop box and both noise tensors (reference draw order: box, rand(N,L), rand(N,L)).
+    `second`: the second view given explicitly (MAE_ViT_MsLd_PAIRED, MAE_ViT_MsLd.py:79-146) instead of the crop."""
     variant = cfg["variant"]
-    crop = crop_resize(imgs, box, cfg["S"])
+    crop = crop_resize(imgs, box, cfg["S"]) if second is None else second
     vo = baseline(sd, cfg, imgs, noise_orig, mask_ratio)
     vc = baseline(sd, cfg, crop, noise_crop, mask_ratio)
     out = dict(imgs_crop=crop, loss_orig=vo["loss"], loss_crop=vc["loss"], pred=vo["pred"], mask=vo["mask"],
@@ -377,10 +378,10 @@ def cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio=0.75, bn=
     return out
 
 
-def forward(sd, cfg, imgs, noise_orig, noise_crop=None, box=None, mask_ratio=0.75, bn=None, training=True):
+def forward(sd, cfg, imgs, noise_orig, noise_crop=None, box=None, mask_ratio=0.75, bn=None, training=True, second=None):
     if cfg["variant"] == "Baseline":
         return baseline(sd, cfg, imgs, noise_orig, mask_ratio)
-    return cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio, bn, training)
+    return cross_scale(sd, cfg, imgs, noise_orig, noise_crop, box, mask_ratio, bn, training, second)
 
 
 # -------------------------------------------------- main_pretrain.py:426-427 (timm add_weight_decay)

@@ -719,6 +719,90 @@ def g_fullsize_n128():
     json.dump(meta, open(os.path.join(OUT, "fullsize_n128.json"), "w"), indent=1)
 
 
+# ------------------------------------------------------------------ G14 input transform
+def g_input_transform():
+    """The reference's own training transform (util/datasets.py:107-136 `BaseDataset.build_transform(True, ...)`) behind its own RGB dataset
+    class (util/datasets.py:161-210: csv -> PIL -> transform) on seeded uint8 images of ragged sizes written as PNG files; the random
+    decisions of every sample (flips, crop box) are recorded next to the output so that the GPU input step can be handed the same ones."""
+    import tempfile
+    from PIL import Image
+    import util.datasets as ref_datasets
+    S = 64
+    mean, std = ref_datasets.Dataset_fmow_rgb.mean, ref_datasets.Dataset_fmow_rgb.std
+    g = torch.Generator().manual_seed(77)
+    sizes = [(97, 120), (150, 130), (64, 64), (120, 200), (33, 47), (80, 64), (200, 90)]
+    d = dict(S=np.array(S), mean=np.array(mean), std=np.array(std), sizes=np.array(sizes))
+    with tempfile.TemporaryDirectory() as tmp:
+        rows = []
+        for n, (h, w) in enumerate(sizes):
+            # smooth + noise content: a bicubic anti-aliased resize of pure noise has little signal left to compare
+            yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+            base = torch.stack([127 + 90 * torch.sin(yy / (5 + c) + n) * torch.cos(xx / (7 - c)) for c in range(3)], -1)
+            img = (base + 30 * torch.randn(h, w, 3, generator=g)).clamp(0, 255).to(torch.uint8)
+            Image.fromarray(img.numpy(), "RGB").save(os.path.join(tmp, f"im{n}.png"))
+            d[f"img{n}"] = npy(img)
+            rows.append((n % 5, f"im{n}.png"))
+        with open(os.path.join(tmp, "train.csv"), "w") as f:
+            f.write("category,image_path\n" + "".join(f"{c},{pth}\n" for c, pth in rows))
+        tf = ref_datasets.BaseDataset.build_transform(True, S, mean, std)
+        with quiet():
+            ds = ref_datasets.Dataset_fmow_rgb(os.path.join(tmp, "train.csv"), tf)
+        params, outs, seeds = [], [], []
+        for rep in range(2):                      # two passes with different seeds: different flips / boxes per image
+            for n, (h, w) in enumerate(sizes):
+                seed = 1000 * rep + n
+                torch.manual_seed(seed)
+                x, label = ds[n]
+                assert label == n % 5 and tuple(x.shape) == (3, S, S)
+                i, j, bh, bw = ref_stubs.RandomResizedCrop.last_box
+                params.append((h, w, i, j, bh, bw, int(ref_stubs.RandomHorizontalFlip.last), int(ref_stubs.RandomVerticalFlip.last)))
+                outs.append(npy(x))
+                seeds.append(seed)
+    d["params"], d["out"], d["seeds"], d["index"] = np.array(params), np.stack(outs), np.array(seeds), np.array([k % len(sizes) for k in range(len(outs))])
+    np.savez_compressed(os.path.join(OUT, "input_transform.npz"), **d)
+
+
+# ------------------------------------------------------------------ G15 two explicit views (MAE_ViT_MsLd.py:79-146)
+def g_paired():
+    """MAE_ViT_MsLd_PAIRED at micro size on the seeded weights of model_micro.npz: two explicit views instead of the crop."""
+    from models_mae.MAE_ViT_MsLd import MAE_ViT_MsLd_PAIRED
+    g = torch.Generator().manual_seed(44)
+    imgs1, imgs2 = torch.randn(4, 3, 64, 64, generator=g), torch.randn(4, 3, 64, 64, generator=g)
+    torch.manual_seed(0)
+    with quiet():
+        fresh = models_mae.MAE_ViT_MsLdCeCd(**MICRO, input_size=64, patch_size="16", predictor_hidden_size=MICRO_HP)
+    sd0 = {k: v.clone() for k, v in fresh.state_dict().items()}
+    d = dict(imgs1=npy(imgs1), imgs2=npy(imgs2))
+    for reduction, kw, tag in (("sum", {}, "sum"), ("mean", dict(mask_seed=11), "mean_seed11")):
+        torch.manual_seed(0)
+        with quiet():
+            model = MAE_ViT_MsLd_PAIRED(**MICRO, input_size=64, patch_size="16", ms_decoder_loss_reduction=reduction)
+        model.load_state_dict({k: v for k, v in sd0.items() if k in model.state_dict()}, strict=True)
+        model.train()
+        params = list(model.named_parameters())
+        draws = []
+        torch.manual_seed(5)
+        with record_rand(draws):
+            out = model(imgs1, imgs2, mask_ratio=0.75, return_embeds=True, **kw)
+        out[0].backward()
+        grads = {n: p.grad.detach().clone() for n, p in params if p.grad is not None}
+        names = sorted(grads)
+        d[f"{tag}_loss"], d[f"{tag}_pred"], d[f"{tag}_mask"] = npy(out[0]), npy(out[1]), npy(out[2])
+        d[f"{tag}_enc_orig"], d[f"{tag}_enc_crop"] = npy(out[3][0]), npy(out[3][1])
+        d[f"{tag}_dec_orig"], d[f"{tag}_dec_crop"] = npy(out[4][0]), npy(out[4][1])
+        for n, t in enumerate(draws):
+            d[f"{tag}_noise{n}"] = npy(t)
+        d[f"{tag}_gradnames"] = np.array(names)
+        d[f"{tag}_gradsq"] = np.array([grads[n].double().pow(2).sum().item() for n in names])
+        d[f"{tag}_gradsum"] = np.array([grads[n].double().sum().item() for n in names])
+        d[f"{tag}_nograd"] = np.array([n for n, p in params if p.requires_grad and p.grad is None])
+        for n in SEL:
+            if n in grads and grads[n].numel() <= 16384:
+                d[f"{tag}_g_{n}"] = npy(grads[n])
+    d["state_keys"] = np.array(sorted(model.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "paired.npz"), **d)
+
+
 def main():
     torch.set_num_threads(8)
     with quiet():
@@ -735,6 +819,8 @@ def main():
     g_vitb()
     g_fullsize()
     g_fullsize_n128()
+    g_input_transform()
+    g_paired()
     for f in sorted(os.listdir(OUT)):
         _print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1024:9.1f} KiB")
 

@@ -99,12 +99,13 @@ class PatchEmbed(nn.Module):
 
 # ----------------------------------------------------------------------- torchvision 0.15.1
 def rrc_get_params(height, width, scale, ratio=(3.0 / 4.0, 4.0 / 3.0)):
-    """Box proposal loop of RandomResizedCrop.get_params (consumes the global CPU torch RNG)."""
+    """Box proposal loop of torchvision 0.15.1 RandomResizedCrop.get_params (consumes the global CPU torch RNG): the log-ratio bounds and
+    the exponential are float32 tensor operations there."""
     area = height * width
-    lo, hi = math.log(ratio[0]), math.log(ratio[1])
+    log_ratio = torch.log(torch.tensor(ratio))
     for _ in range(10):
         target = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
-        ar = math.exp(torch.empty(1).uniform_(lo, hi).item())
+        ar = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
         w = int(round(math.sqrt(target * ar)))
         h = int(round(math.sqrt(target / ar)))
         if 0 < w <= width and 0 < h <= height:
@@ -123,18 +124,90 @@ def rrc_get_params(height, width, scale, ratio=(3.0 / 4.0, 4.0 / 3.0)):
     return (height - h) // 2, (width - w) // 2, h, w
 
 
+class InterpolationMode:
+    """torchvision.transforms.InterpolationMode: the two members the reference names (util/datasets.py:111, MAE_ViT_MsLd.py default)."""
+    BILINEAR = "bilinear"
+    BICUBIC = "bicubic"
+
+
 class RandomResizedCrop(nn.Module):
+    """torchvision 0.15.1 RandomResizedCrop on tensors: get_params, then F.resized_crop = crop + `interpolate(mode, align_corners=False,
+    antialias)` on the float image (no clamp for float inputs).  Used by the models (bilinear, MAE_ViT_MsLd.py:29-35) and by the
+    dataset transform (bicubic, util/datasets.py:124-131)."""
     last_box = None  # recorded for fixtures
 
-    def __init__(self, size, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), antialias=None, **_):
+    def __init__(self, size, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), interpolation=InterpolationMode.BILINEAR, antialias=None, **_):
         super().__init__()
-        self.size, self.scale, self.ratio, self.antialias = tuple(size), tuple(scale), tuple(ratio), antialias
+        size = (int(size), int(size)) if isinstance(size, (int, float)) else tuple(size)
+        self.size, self.scale, self.ratio, self.interpolation, self.antialias = size, tuple(scale), tuple(ratio), interpolation, antialias
 
     def forward(self, img):
         i, j, h, w = rrc_get_params(img.shape[-2], img.shape[-1], self.scale, self.ratio)
         RandomResizedCrop.last_box = (i, j, h, w)
-        return F.interpolate(img[..., i:i + h, j:j + w], size=self.size, mode="bilinear",
-                             align_corners=False, antialias=bool(self.antialias))
+        batched = img.dim() == 4
+        x = img[..., i:i + h, j:j + w]
+        y = F.interpolate(x if batched else x[None], size=self.size, mode=self.interpolation, align_corners=False, antialias=bool(self.antialias))
+        return y if batched else y[0]
+
+
+class ToTensor:
+    """torchvision F.to_tensor for a PIL image of mode RGB / L: uint8 HWC -> float32 CHW / 255."""
+
+    def __call__(self, pic):
+        import numpy as np
+        a = np.array(pic, np.uint8, copy=True)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return torch.from_numpy(a).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+
+class Normalize:
+    def __init__(self, mean, std, inplace=False):
+        self.mean, self.std = mean, std
+
+    def __call__(self, t):
+        mean = torch.as_tensor(self.mean, dtype=t.dtype).view(-1, 1, 1)
+        std = torch.as_tensor(self.std, dtype=t.dtype).view(-1, 1, 1)
+        return t.clone().sub_(mean).div_(std)
+
+
+class _RandomFlip(nn.Module):
+    """RandomHorizontalFlip / RandomVerticalFlip: `if torch.rand(1) < p: flip` (one draw from the global CPU generator each)."""
+    dim = -1
+    last = None  # recorded for fixtures
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, img):
+        hit = bool(torch.rand(1) < self.p)
+        type(self).last = hit
+        return img.flip(self.dim) if hit else img
+
+
+class RandomHorizontalFlip(_RandomFlip):
+    dim = -1
+
+
+class RandomVerticalFlip(_RandomFlip):
+    dim = -2
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, img):
+        for t in self.transforms:
+            img = t(img)
+        return img
+
+
+def _eval_only(name):
+    def ctor(*a, **k):
+        raise NotImplementedError(f"torchvision.transforms.{name}: the eval transform (util/datasets.py:138-158) is outside the hot path — not restated")
+    return ctor
 
 
 # --------------------------------------------------------------------------------- install
@@ -212,7 +285,18 @@ def install():
     _mod("pytorch_msssim", ssim=msssim_ssim, ms_ssim=msssim_ms_ssim)
     _mod("wandb", log=lambda *a, **k: None)
     tv = _mod("torchvision")
-    tv.transforms = _mod("torchvision.transforms", RandomResizedCrop=RandomResizedCrop)
+    tv.transforms = _mod("torchvision.transforms", RandomResizedCrop=RandomResizedCrop, InterpolationMode=InterpolationMode, ToTensor=ToTensor,
+                         Normalize=Normalize, RandomHorizontalFlip=RandomHorizontalFlip, RandomVerticalFlip=RandomVerticalFlip, Compose=Compose,
+                         Resize=_eval_only("Resize"), CenterCrop=_eval_only("CenterCrop"))
+    # util/datasets.py:10-21 imports the multi-band readers' packages at module level; nothing on the RGB path calls into them
+    import logging as _logging
+    rio = _mod("rasterio", logging=_logging)
+    rio.transform = _mod("rasterio.transform", Affine=dummy)
+    rio.crs = _mod("rasterio.crs", CRS=dummy)
+    rio.features = _mod("rasterio.features", rasterize=dummy)
+    fio = _mod("fiona")
+    fio.errors = _mod("fiona.errors", FionaValueError=type("FionaValueError", (ValueError,), {}))
+    fio.transform = _mod("fiona.transform", transform_geom=dummy)
     for missing in ("models_mae_cross", "models_mae_crossv2", "models_mae_shunted", "models_mae_shunted_cross"):
         _mod("models_mae." + missing)
     torch.cuda.synchronize = lambda *a, **k: None  # engine_pretrain.py:72 hard-requires a GPU otherwise

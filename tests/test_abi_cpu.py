@@ -29,8 +29,13 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/csmae.h but not exported"
     assert set(decl) == set(csmae_hip.exported_symbols())
+    # ... and nothing else: the dynamic symbol table of the library (`nm -D`) holds exactly the declared csmae_* functions
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", csmae_hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()[-2:-1] == ["T"] and ln.split()[-1].startswith("csmae_")}
+    assert exported == set(decl), (sorted(exported - set(decl)), sorted(set(decl) - exported))
     lib.csmae_abi_version.restype = ctypes.c_int
-    assert lib.csmae_abi_version() == 4
+    assert lib.csmae_abi_version() == csmae_hip.ABI_VERSION == 5
 
 
 def test_binding_arity_matches_header():

@@ -116,6 +116,59 @@ def test_micro_variants_fp32_vs_reference_and_oracle(tag):
         np.testing.assert_allclose(eng.ws.imgs_crop.cpu().numpy(), oout["imgs_crop"].numpy(), rtol=0, atol=5e-6)
 
 
+@pytest.mark.parametrize("tag,kw", [("sum", {}), ("mean_seed11", dict(mask_seed=11))])
+def test_paired_two_explicit_views_vs_reference_and_oracle(tag, kw):
+    """MAE_ViT_MsLd_PAIRED (MAE_ViT_MsLd.py:79-146): two explicit views instead of the crop, against the reference's own run
+    (tests/golden/paired.npz) and, gradient by gradient, against the oracle."""
+    import csmae_oracle as O
+    import models_mae
+    d, p = load("model_micro.npz"), load("paired.npz")
+    sd = micro_sd(d)
+    red = "mean" if tag.startswith("mean") else "sum"
+    m = models_mae.MAE_ViT_MsLd_PAIRED(**MICRO, input_size=64, patch_size="16", ms_decoder_loss_reduction=red)
+    assert sorted(m.state_dict().keys()) == [str(k) for k in p["state_keys"]]
+    m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()}, strict=True)
+    m = m.cuda().train()
+    i1, i2 = T(p["imgs1"]), T(p["imgs2"])
+    noise = [T(p[f"{tag}_noise0"]), T(p[f"{tag}_noise1"])]
+    if kw:   # seeded: the model draws its own noise on the device generator — inject the reference's CPU draws, but check the seeding rule
+        assert torch.equal(noise[0], noise[1])
+    m._test_draws = dict(noise=noise, box=None)
+    out = m(i1.cuda(), i2.cuda(), mask_ratio=0.75, return_embeds=True, **kw)
+    loss = out[0]
+    assert rel(loss, p[f"{tag}_loss"]) < LOSS_RTOL, (float(loss), float(p[f"{tag}_loss"]))
+    assert np.array_equal(out[2].cpu().numpy(), p[f"{tag}_mask"])
+    np.testing.assert_allclose(out[1].detach().cpu().numpy(), p[f"{tag}_pred"], rtol=1e-3, atol=2e-5)
+    for k, o in (("enc_orig", out[3][0]), ("enc_crop", out[3][1]), ("dec_orig", out[4][0]), ("dec_crop", out[4][1])):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), p[f"{tag}_{k}"], rtol=1e-3, atol=3e-5, err_msg=k)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for n, sq in zip([str(n) for n in p[f"{tag}_gradnames"]], p[f"{tag}_gradsq"]):
+        got = params[n].grad.double().pow(2).sum().item()
+        assert abs(got - sq) <= 2e-3 * sq + 1e-14, (n, got, sq)
+    assert sorted(n for n, q in params.items() if q.requires_grad and q.grad is None) == sorted(str(n) for n in p[f"{tag}_nograd"])
+    for k in p.files:
+        if k.startswith(f"{tag}_g_"):
+            ref = p[k]
+            np.testing.assert_allclose(params[k[len(tag) + 3:]].grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max() + 1e-9, err_msg=k)
+    osd = O.trainable_copy({k: v for k, v in sd.items() if k in m.state_dict()})
+    cfg = O.make_cfg(input_size=64, patch_size=16, variant="MsLd", ms_decoder_loss_reduction=red, **MICRO)
+    oout = O.forward(osd, cfg, i1, noise[0], noise[1], None, 0.75, None, second=i2)
+    oout["loss"].backward()
+    assert rel(loss, oout["loss"]) < 2e-5
+    for n, q in params.items():
+        if q.grad is not None:
+            ref = osd[n].grad
+            np.testing.assert_allclose(q.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-4 * ref.abs().max().item() + 1e-9, err_msg=n)
+    # without injected draws: the seeding rule of the reference (both views masked alike under mask_seed / consistent_mask)
+    m.zero_grad()
+    out2 = m(i1.cuda(), i2.cuda(), mask_ratio=0.75, mask_seed=3)
+    eng = m._engines[torch.float32]
+    assert torch.equal(eng.ws.mask[:4], eng.ws.mask[4:]) and torch.isfinite(out2[0])
+    with pytest.raises(AssertionError):
+        m(i1.cuda(), i2[:, :, :32].cuda())
+
+
 def test_micro_two_fused_adamw_steps_fp32():
     from csmae_hip.optim import FusedAdamW, add_weight_decay
     d = load("model_micro.npz")

@@ -1135,6 +1135,15 @@ def test_augment_u8_matches_reference_transform_chain():
             want = O.train_transform(im, pr, mean, std, S)
             err = (out[n] - want).abs().max().item()
             assert err < 2e-4, (C, S, n, err)
+    # ... and against the REFERENCE's own chain (util/datasets.py:107-136 behind Dataset_fmow_rgb), tests/golden/input_transform.npz
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "input_transform.npz"))
+    S, idx = int(d["S"]), [int(v) for v in d["index"]]
+    aug = GpuAugment(S, [float(v) for v in d["mean"]], [float(v) for v in d["std"]])
+    out = aug([torch.from_numpy(d[f"img{i}"]) for i in idx], [tuple(int(v) for v in p) for p in d["params"]]).cpu().numpy()
+    assert out.shape == d["out"].shape
+    for n in range(out.shape[0]):
+        err = np.abs(out[n] - d["out"][n]).max()
+        assert err < 2e-4, (n, d["params"][n], err)
     # the parameter draw consumes the CPU RNG in the reference's order and stays inside the image
     torch.manual_seed(0)
     for H, W in ((224, 224), (1000, 700), (50, 400)):
