@@ -208,10 +208,36 @@ def main():
         dist.all_reduce(lmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(lmax, op=dist.ReduceOp.MAX)
         sync = wrapped._sync
+        # What the exchange costs the step (the first multi-GPU run must explain itself; nobody can re-run it by hand): (a) per-bucket
+        # times from HIP events on the exchange stream over one more step, (b) the same K steps once more WITHOUT the collectives
+        # (`no_sync`: every rank steps on its local gradients — the replicas diverge, which is why the weight checksum above was taken
+        # first): exposed communication per step = ms_with - ms_without.
+        buckets = None
+        if sync is not None:
+            sync.timing = True
+            step()
+            per = sync.bucket_times()
+            sync.timing = False
+            buckets = [{"elements": int(n), "ms": round(ms, 3)} for n, ms in per]
+        fence()
+        t1 = time.perf_counter()
+        with wrapped.no_sync():
+            for _ in range(a.steps):
+                step()
+        fence()
+        nosync = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        dist.all_reduce(nosync, op=dist.ReduceOp.MAX)
+        ms_with, ms_without = 1e3 * float(tmax) / a.steps, 1e3 * float(nosync) / a.steps
         dp_check = {"ranks_seen": int(ones.item()), "ms_per_step_min": round(1e3 * float(tmin) / a.steps, 3), "ms_per_step_max": round(1e3 * float(tmax) / a.steps, 3),
                     "weights_checksum_spread": float(cmax - cmin), "loss_min": round(float(lmin), 5), "loss_max": round(float(lmax), 5),
                     "grad_payload": "bf16" if (sync is not None and sync._staging is not None) else "fp32",
-                    "buckets_per_step": len(sync.issued) if sync is not None else 0, "backend": a.backend}
+                    "buckets_per_step": len(buckets) if buckets is not None else 0, "backend": a.backend,
+                    "ms_per_step_without_collectives": round(ms_without, 3), "exposed_comm_ms": round(ms_with - ms_without, 3),
+                    "bucket_allreduce": buckets, "bucket_allreduce_ms_sum": round(sum(b["ms"] for b in buckets), 3) if buckets else 0.0,
+                    # knobs a real multi-GPU run should re-measure: RCCL's queue priority, and its channel count = the CUs its
+                    # kernels take from the GEMMs (a CU mask cannot confine them: torch's ProcessGroupNCCL launches on a stream of its own,
+                    # and static CU partitions measured slower than time-slicing on one GPU — DESIGN §5)
+                    "rccl_env": {k: os.environ.get(k) for k in ("TORCH_NCCL_HIGH_PRIORITY", "NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")}}
         elapsed = tmax
     elapsed = float(elapsed)
     final_loss = float(loss.detach())

@@ -55,8 +55,8 @@ _SIGNATURES = {
     "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],
     "csmae_rows_gather_idx": [L, I, I, I, P, P, L, P, P],
     "csmae_target_minmax": [I, L, I, I, I, I, P, P, P, P, P],
-    "csmae_recon_loss_fwd": [I, I, L, I, I, I, I, P, P, P, L, P, P, P],
-    "csmae_recon_loss_bwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P, F, P, P, L, P],
+    "csmae_recon_loss_fwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P],
+    "csmae_recon_loss_bwd": [I, I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P, F, P, P, L, P],
     "csmae_ssim_workspace_floats": [L, I, I, I, I, P],
     "csmae_ssim_fwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P],
     "csmae_ssim_apply": [I, I, F, F, P, P, P],

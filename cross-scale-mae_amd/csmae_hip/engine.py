@@ -161,7 +161,9 @@ class Workspace:
         self.emb_lp = E(Md, Dd, **lp)
         self.emb32 = E(Md, Dd, **f32)
         self.dn_st = E(2, Md, **f32)
-        self.pred = E(Md, c["P"], **f32)
+        # decoder_pred's output: bf16 in throughput mode (what autocast hands the reference's loss; the reconstruction head reads it twice and the
+        # product writes it once: 155 -> 77 MB each), fp32 in parity mode and for the ssim family (its kernels take fp32 planes)
+        self.pred = E(Md, c["P"], **(lp if (T != torch.float32 and c["loss"] not in SSIM_KINDS and c["P"] % 8 == 0 and not os.environ.get("CSMAE_PRED_FP32")) else f32))
         self.rowloss = E(B2 * L, **f32)
         self.minmax = E(4, **f32)
         self.mm_scratch = E(B2 * L * 2, **f32) if c["loss"] == "bce" else None
@@ -730,6 +732,31 @@ class Engine:
             self.aux = torch.cuda.Stream()
         ce_done = None
 
+        kind, npx = c["loss"], c["norm_pix"]
+        ssim = SSIM_KINDS.get(kind)
+        if ssim is not None:  # MAE_ViT_Shared.py:165-267: (per-patch kind, pyramid levels, weight); the term joins `losses` after finalize
+            kind = ssim[0]
+        # Loss heads per view, each on its view's stream: the reconstruction term of a view needs only that view's prediction, and the
+        # cross-decoder predictor (MAE_ViT_MsLdCeCd.py:57: gather -> Linear -> BatchNorm/ReLU -> Linear) only the crop's decoder output —
+        # they run behind their trunk instead of behind the join of both (where one stream idles until the other arrives).  Only when a
+        # chunk IS a view and the per-patch kind needs no whole-tensor statistics (bce's min / max, the ssim family).
+        nch = int(os.environ.get("CSMAE_FWD_CHUNKS", "2"))  # tuning aid: independent sample chunks in flight (2 = one per view)
+        if nch < 2 or B2 % nch:
+            nch = 2
+        lead = self._fwd_lead if (two and nch == 2 and not self.fp8 and 0 < B2 // nch + self._fwd_lead < B2) else 0   # (fp8: the staging buffers of a chunk hold half a batch)
+        view_heads = (two and nch == 2 and lead == 0 and ssim is None and kind in ("mse", "l2", "mae", "l1") and not os.environ.get("CSMAE_HEADS_JOINED"))
+
+        emb_ready = []
+
+        def predictor_fwd(st):
+            bn = "predictor.1."
+            mod = self.module.predictor[1]
+            ops.rows_gather(ws.emb32, ws.pin, L, Td, N * Td + 1, st=st)
+            ops.gemm(ws.pin, self.W("predictor.0.weight"), ws.u, bias=P("predictor.0.bias"), st=st)
+            ops.bnrelu_fwd(ws.u, P(bn + "weight"), P(bn + "bias"), ws.r, ws.bn_st[0], ws.bn_st[1], N, L, mod.running_mean, mod.running_var,
+                           mod.num_batches_tracked, eps=mod.eps, momentum=mod.momentum, training=training, st=st)
+            ops.gemm(ws.r, self.W("predictor.3.weight"), ws.v, bias=P("predictor.3.bias"), st=st)
+
         def trunk(b0, nb, st, stream_obj, evs):
             """Encoder -> decoder -> prediction for samples [b0, b0 + nb), as a generator that yields after every block so that the
             trunks of several streams are enqueued round-robin (a stream whose kernels are enqueued only after another stream's
@@ -761,23 +788,28 @@ class Engine:
                 yield
             ops.layernorm_fwd(ws.dec["x"][c["Nd"]][rd_], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp[rd_], ws.dn_st[0][rd_],
                               ws.dn_st[1][rd_], y32=ws.emb32[rd_], st=st)
+            if view_heads and b0 > 0 and self.has_pred:   # the crop's decoder output exists: the predictor (on the main stream, below) may start
+                emb_ready.append(torch.cuda.Event())
+                emb_ready[0].record(stream_obj)
             ops.gemm(ws.emb_lp[rd_], self._w_pred()[: c["P"]], ws.pred[rd_], bias=P("decoder_pred.bias"), st=st)
+            if view_heads:   # (a chunk is a view here: samples [0, N) = the original, [N, 2N) = the crop)
+                ops.recon_loss_fwd(kind, npx, img0 if b0 == 0 else img1, None, ws.pred[rd_], None, ws.rowloss[b0 * L:(b0 + nb) * L], nb, nb,
+                                   c["C"], c["S"], c["p"], mask=ws.mask[b0:b0 + nb], st=st)
 
         if two:
             # The two views are independent until the losses: view 1 runs on the second stream.  Its kernels fill the CUs that view
             # 0's partial waves, attention and LayerNorm kernels leave idle (same effect as the weight-gradient stream in backward).
-            nch = int(os.environ.get("CSMAE_FWD_CHUNKS", "2"))  # tuning aid: independent sample chunks in flight (2 = one per view)
-            if nch < 2 or B2 % nch:
-                nch = 2
             while len(self._fwd_streams) < nch - 1:
                 self._fwd_streams.append(self.side if (not self._fwd_streams and not getattr(self, "_side_masked", False)) else torch.cuda.Stream())
             per = B2 // nch
             # the main stream starts first (the other ones wait for the stem) and would idle at the join: it takes `_fwd_lead` samples more
             # than its share (chunks are sample ranges: attention, LayerNorm and the GEMM rows do not care where a view ends)
-            lead = self._fwd_lead if (nch == 2 and not self.fp8 and 0 < per + self._fwd_lead < B2) else 0   # (fp8: the staging buffers of a chunk hold half a batch)
             cuts = [0, per + lead] + [k * per for k in range(2, nch)] + [B2]
             for so in self._fwd_streams[: nch - 1]:
                 so.wait_stream(main)         # (the stem; and the previous step's readers of the workspace)
+            if self.has_ce:
+                self.aux.wait_stream(main)   # (workspace reuse: the previous step's backward read E / zc on the main stream) — BEFORE the trunks are
+                                             # enqueued: the contrastive branch then starts when both encoders are done, under the decoders' GEMMs
             evs = []
             gens = [trunk(0, cuts[1], st, main, evs)] + [trunk(cuts[k], cuts[k + 1] - cuts[k], self._fwd_streams[k - 1].cuda_stream, self._fwd_streams[k - 1], evs)
                                                           for k in range(1, nch)]
@@ -786,15 +818,25 @@ class Engine:
                     for _ in g:
                         pass
                 gens = []
-            while gens:
-                gens = [g for g in gens if next(g, StopIteration) is not StopIteration]
-            if self.has_ce:
-                self.aux.wait_stream(main)  # (workspace reuse: the previous step's backward read E / zc on the main stream)
+
+            def contrastive():
                 for ev in evs:
                     self.aux.wait_event(ev)
                 ops.ntxent_fwd(lat_heads, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
-                ce_done = torch.cuda.Event()
-                ce_done.record(self.aux)
+                done = torch.cuda.Event()
+                done.record(self.aux)
+                return done
+            while gens:
+                gens = [g for g in gens if next(g, StopIteration) is not StopIteration]
+                if self.has_ce and ce_done is None and len(evs) == nch:   # both encoders are enqueued: the contrastive branch goes out now
+                    ce_done = contrastive()
+            if self.has_ce and ce_done is None:
+                ce_done = contrastive()
+            if view_heads and self.has_pred:
+                # the predictor behind the main stream's own trunk, as soon as the crop's decoder_norm output exists: the second stream
+                # still has its decoder_pred product and reconstruction term to do, and neither stream waits for the other's tail
+                main.wait_event(emb_ready[0])
+                predictor_fwd(st)
             for so in self._fwd_streams[: nch - 1]:
                 main.wait_stream(so)
         else:
@@ -810,29 +852,21 @@ class Engine:
                     ops.ntxent_fwd(lat_heads, ws.zc, ws.inv_norm, ws.E, ws.neg, ws.ce_rowloss, N, Te, keep, st=self.aux.cuda_stream)
                     ce_done = torch.cuda.Event()
                     ce_done.record(self.aux)
-        kind, npx = c["loss"], c["norm_pix"]
         mm = None
-        ssim = SSIM_KINDS.get(kind)
-        if ssim is not None:  # MAE_ViT_Shared.py:165-267: (per-patch kind, pyramid levels, weight); the term joins `losses` after finalize
-            kind = ssim[0]
+        if ssim is not None:
             ops.ssim_fwd(ssim[1], npx, img0, img1, ws.pred, ws.mask, ws.ssim_ws, ws.ssim_terms, B2, N, c["C"], c["S"], c["p"], st=st)
         if kind == "bce":
             ops.target_minmax(img0, img1, ws.mm_scratch, ws.minmax, B2, N, c["C"], c["S"], c["p"], npx, st=st)
             mm = ws.minmax
         if kind == "none":
             ws.rowloss.zero_()
-        else:
-            ops.recon_loss_fwd(kind, npx, img0, img1, ws.pred, mm, ws.rowloss, B2, N, c["C"], c["S"], c["p"], st=st)
+        elif not view_heads:
+            ops.recon_loss_fwd(kind, npx, img0, img1, ws.pred, mm, ws.rowloss, B2, N, c["C"], c["S"], c["p"], mask=ws.mask, st=st)
         kw = {}
         if self.has_pred:
             kcd = c["loss_cd"]
-            bn = "predictor.1."
-            mod = self.module.predictor[1]
-            ops.rows_gather(ws.emb32, ws.pin, L, Td, N * Td + 1, st=st)
-            ops.gemm(ws.pin, self.W("predictor.0.weight"), ws.u, bias=P("predictor.0.bias"), st=st)
-            ops.bnrelu_fwd(ws.u, P(bn + "weight"), P(bn + "bias"), ws.r, ws.bn_st[0], ws.bn_st[1], N, L, mod.running_mean, mod.running_var,
-                           mod.num_batches_tracked, eps=mod.eps, momentum=mod.momentum, training=training, st=st)
-            ops.gemm(ws.r, self.W("predictor.3.weight"), ws.v, bias=P("predictor.3.bias"), st=st)
+            if not view_heads:
+                predictor_fwd(st)
             ops.pair_loss_fwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.cd_partial, st=st)
             kw.update(cd_partial=ws.cd_partial, cd_scale=self._pair_scale(kcd, N * L, Dd))
         if self.has_le:
@@ -913,7 +947,11 @@ class Engine:
             self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], N, ws.Td)
         ops.layernorm_fwd(ws.dec["x"][c["Nd"]], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp, ws.dn_st[0], ws.dn_st[1], y32=ws.emb32, st=st)
         ops.gemm(ws.emb_lp, self._w_pred()[: c["P"]], ws.pred, bias=P("decoder_pred.bias"), st=st)
-        return ws.pred.view(N, ws.Td, c["P"])[:, 1:, :].clone(), ws.emb32.view(N, ws.Td, Dd).clone()
+        pred = ws.pred
+        if pred.dtype != torch.float32:   # (throughput mode writes bf16 predictions; the stand-alone decoder returns fp32 like its latent input)
+            pred = torch.empty(ws.pred.shape, device=self.device, dtype=torch.float32)
+            ops.cast_f32(ws.pred, pred, st=st)
+        return pred.view(N, ws.Td, c["P"])[:, 1:, :].clone(), ws.emb32.view(N, ws.Td, Dd).clone()
 
     @staticmethod
     def _pair_scale(kind, rows, D):

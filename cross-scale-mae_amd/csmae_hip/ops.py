@@ -87,7 +87,11 @@ def cu_masked_stream(lo: int, hi: int, total_cus: int = 256):
 class launch_done:
     """`with launch_done(ev, st): <one op>` — the op's kernel carries the torch event `ev` as its own completion signal (csmae_next_launch_event)
     instead of a marker packet recorded behind it on stream `st`; ops whose launch site does not support that get the plain record.  `ev` must
-    have been recorded once before (torch creates the HIP event at its first record)."""
+    have been recorded once before (torch creates the HIP event at its first record).
+    Contract (csrc: every CSMAE_LAUNCH site): the event goes to the FIRST CSMAE_LAUNCH kernel issued inside the block, so the wrapped ABI call
+    must issue that kernel LAST — a call that launched anything behind it (a split-K fold, a trailing quantisation) would release the waiter
+    before its output is complete.  True of the three users (csmae_gemm / csmae_gemm_fp8: pipelined kernel last, quantisation passes in
+    front through plain launches; csmae_attn_bwd: one kernel)."""
 
     def __init__(self, ev, st):
         self.h, self.st = ev.cuda_event, st
@@ -96,7 +100,9 @@ class launch_done:
         check(load().csmae_next_launch_event(self.h), "csmae_next_launch_event")
 
     def __exit__(self, *exc):
-        check(load().csmae_flush_launch_event(self.st), "csmae_flush_launch_event")
+        rc = load().csmae_flush_launch_event(self.st)
+        if exc[0] is None:   # (an exception already on its way out of the body is the one to report: never replace it with the flush's)
+            check(rc, "csmae_flush_launch_event")
         return False
 
 
@@ -374,13 +380,14 @@ def target_minmax(img0, img1, scratch, out, B2, N, C, S, p, norm_pix, st=None):
           "csmae_target_minmax")
 
 
-def recon_loss_fwd(kind, norm_pix, img0, img1, pred, minmax, rowloss, B2, N, C, S, p, st=None):
-    check(load().csmae_recon_loss_fwd(LOSS_KINDS[kind], int(norm_pix), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0), _p(minmax),
-                                      _p(rowloss), st if st is not None else stream()), "csmae_recon_loss_fwd")
+def recon_loss_fwd(kind, norm_pix, img0, img1, pred, minmax, rowloss, B2, N, C, S, p, mask=None, st=None):
+    """pred: fp32 or bf16 [B2 * (L + 1), >= P]; mask (optional, [B2 * L] fp32): patches with mask 0 are skipped (rowloss 0)."""
+    check(load().csmae_recon_loss_fwd(LOSS_KINDS[kind], int(norm_pix), dt(pred), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0), _p(minmax),
+                                      _p(mask), _p(rowloss), st if st is not None else stream()), "csmae_recon_loss_fwd")
 
 
 def recon_loss_bwd(kind, norm_pix, img0, img1, pred, minmax, mask, losses, gout, vscale, dpred, B2, N, C, S, p, extra=None, st=None):
-    check(load().csmae_recon_loss_bwd(LOSS_KINDS[kind], int(norm_pix), dt(dpred), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0),
+    check(load().csmae_recon_loss_bwd(LOSS_KINDS[kind], int(norm_pix), dt(dpred), dt(pred), B2, N, C, S, p, _p(img0), _p(img1), _p(pred), pred.stride(0),
                                       _p(minmax), _p(mask), _p(losses), _p(gout), vscale, _p(extra), _p(dpred), dpred.stride(0),
                                       st if st is not None else stream()), "csmae_recon_loss_bwd")
 

@@ -33,6 +33,8 @@ class GradSync:
         self.stream = torch.cuda.Stream() if self.cuda else None
         self._staging = torch.empty(flat_grad.numel(), dtype=comm_dtype, device=flat_grad.device) if comm_dtype not in (None, flat_grad.dtype) else None
         self._pending = False
+        self.timing = False   # bench.py: HIP events around every bucket's exchange on the exchange stream (bucket_times())
+        self._timed = []
         self.issued = []   # (lo, hi) of the ranges exchanged by the current / last backward pass: cleared by the first reduce_range() after a finish() (tests read it)
         self._fresh = True
         # gloo has no AVG; RCCL does
@@ -54,7 +56,13 @@ class GradSync:
             if also is not None:
                 self.stream.wait_stream(also)
             with torch.cuda.stream(self.stream):
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 self._reduce(seg, lo, hi)
+                if self.timing:
+                    e1.record(self.stream)
+                    self._timed.append((lo, hi, e0, e1))
             self._pending = True
         else:
             self._reduce(seg, lo, hi)
@@ -80,6 +88,16 @@ class GradSync:
         else:
             dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
             seg.div_(self.world)
+
+    def bucket_times(self):
+        """[(elements, ms)] per exchanged range since timing was switched on, in issue order: the time between the exchange stream reaching
+        the bucket (its producers done) and the collective's completion on that stream — the ring time plus whatever the collective's
+        kernels wait for CUs.  Synchronises."""
+        if self.cuda:
+            torch.cuda.synchronize()
+        out = [(hi - lo, e0.elapsed_time(e1)) for lo, hi, e0, e1 in self._timed]
+        self._timed = []
+        return out
 
     def finish(self):
         """Make the reduced gradients visible to the current stream (the optimizer's stream)."""

@@ -78,34 +78,37 @@ __global__ __launch_bounds__(1024) void minmax_reduce_kernel(long long per_view,
   }
 }
 
-// rowloss[n2*L + l] = mean/sum_e f(pred[n2, 1+l, e], target)
+// rowloss[n2*L + l] = mean/sum_e f(pred[n2, 1+l, e], target).  `mask` (nullable): patches with mask 0 are skipped (rowloss 0) — the
+// loss only weighs masked patches (MAE_ViT_Shared.py:113-120), three quarters of them at mask_ratio 0.75.
+template <typename TP>
 __global__ __launch_bounds__(256) void recon_fwd_kernel(PatchGeom g, int kind, int norm_pix, long long patches, const float* __restrict__ img0,
-                                                        const float* __restrict__ img1, const float* __restrict__ pred, long long ldp,
-                                                        const float* __restrict__ minmax, float* __restrict__ rowloss) {
+                                                        const float* __restrict__ img1, const TP* __restrict__ pred, long long ldp,
+                                                        const float* __restrict__ minmax, const float* __restrict__ mask, float* __restrict__ rowloss) {
   const int lane = threadIdx.x & 63;
   const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pt >= patches) return;
+  if (mask && mask[pt] == 0.f) { if (lane == 0) rowloss[pt] = 0.f; return; }
   const long long n2 = pt / g.L; const int l = (int)(pt - n2 * g.L);
   const float* img = patch_img(g, img0, img1, n2);
   float mu = 0.f, rs = 1.f;
   if (norm_pix) patch_stats(g, img, l, lane, mu, rs);
   float lo = 0.f, sc = 1.f;
   if (kind == LOSS_BCE) { int v = (int)(n2 / g.N); lo = minmax[v * 2]; sc = 1.f / (minmax[v * 2 + 1] - lo + 1.0e-6f); }
-  const float* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
+  const TP* pr = pred + (n2 * (g.L + 1) + 1 + l) * ldp;
   float s = 0.f;
   for (int e = lane; e < g.P; e += 64) {
     float t = (patch_elem(g, img, l, e) - mu) * rs;
     if (kind == LOSS_BCE) t = (t - lo) * sc;
-    s += elem_loss(kind, pr[e], t);
+    s += elem_loss(kind, ld_as_f32<TP>(pr + e), t);
   }
   s = wave_sum(s);
   if (lane == 0) rowloss[pt] = mean_over_last(kind) ? s / g.P : s;
 }
 // dpred[n2, 1+l, e] = gout * vscale * mask / masksum(view) * f'(pred, t) / (P or 1) (+ extra[n2, l, e], the ssim family's share,
 // already scaled, which also reaches visible patches through scale_01's min / max) ; cls rows and pad columns are zeroed
-template <typename T>
+template <typename T, typename TP>
 __global__ __launch_bounds__(256) void recon_bwd_kernel(PatchGeom g, int kind, int norm_pix, long long rows, const float* __restrict__ img0,
-                                                        const float* __restrict__ img1, const float* __restrict__ pred, long long ldp,
+                                                        const float* __restrict__ img1, const TP* __restrict__ pred, long long ldp,
                                                         const float* __restrict__ minmax, const float* __restrict__ mask,
                                                         const float* __restrict__ losses, const float* __restrict__ gout, float vscale,
                                                         const float* __restrict__ extra, T* __restrict__ dpred, long long ldd) {
@@ -124,17 +127,108 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(PatchGeom g, int kind, i
   float lo = 0.f, sc = 1.f;
   if (kind == LOSS_BCE) { lo = minmax[v * 2]; sc = 1.f / (minmax[v * 2 + 1] - lo + 1.0e-6f); }
   const float coef = gout[0] * vscale * m / losses[6 + v] / (mean_over_last(kind) ? (float)g.P : 1.f);
-  const float* pr = pred + row * ldp;
+  const TP* pr = pred + row * ldp;
   for (int e = lane; e < ldd; e += 64) {
     float o = 0.f;
     if (e < g.P) {
       float t = (patch_elem(g, img, l, e) - mu) * rs;
       if (kind == LOSS_BCE) t = (t - lo) * sc;
-      o = coef * elem_grad(kind, pr[e], t);
+      o = coef * elem_grad(kind, ld_as_f32<TP>(pr + e), t);
       if (ex) o += ex[e];
     }
     st_from_f32<T>(dp + e, o);
   }
+}
+
+// ---- throughput forms of the two kernels above for the geometry the step spends its time in: bf16 predictions and bf16 dpred, C * p * p a
+// multiple of 128 (ViT-*/16 RGB: P = 768; 4-band: 1024), the mse / l2 / mae / l1 kinds.  A wave owns a patch; a lane owns the element PAIRS
+// e = 2 lane + 128 it: the prediction row is read as one 4-byte load per pair (whole 256-byte lines per wave instruction), the 2 NP image
+// values of a lane are independent gathers that are all in flight before the first use (the generic form walks the patch with a runtime
+// trip count: one dependent load pair per iteration), and the image is read ONCE also under norm_pix_loss (the values stay in registers
+// for the statistics).  Same per-element arithmetic as the generic kernels (the partial sums are taken in another order).
+template <int C, int P_, int NP>
+__device__ __forceinline__ void patch_load_pairs(const PatchGeom& g, const float* __restrict__ img, int l, int lane, float (&t)[2 * NP]) {
+  const int gh = l / g.G, gw = l - gh * g.G;
+  const float* base = img + ((long long)gh * P_) * g.S + gw * P_;
+#pragma unroll
+  for (int it = 0; it < NP; ++it)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = 2 * lane + 128 * it + k, r = e / C, c = e - r * C, ph = r / P_, pw = r - ph * P_;
+      t[2 * it + k] = base[((long long)c * g.S + ph) * g.S + pw];
+    }
+}
+template <int NV>
+__device__ __forceinline__ void patch_normalise(int P, float (&t)[NV], float& mu, float& rs) {   // norm_pix_loss: unbiased variance, eps 1e-6
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s += t[k];
+  mu = wave_sum(s) / P;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { const float d = t[k] - mu; q += d * d; }
+  rs = rsqrtf(wave_sum(q) / (P - 1) + 1.0e-6f);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) t[k] = (t[k] - mu) * rs;
+}
+template <int C, int P_, int NP>
+__global__ __launch_bounds__(256) void recon_fwd_fast_kernel(PatchGeom g, int kind, int norm_pix, long long patches, const float* __restrict__ img0,
+                                                             const float* __restrict__ img1, const bf16_t* __restrict__ pred, long long ldp,
+                                                             const float* __restrict__ mask, float* __restrict__ rowloss) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= patches) return;
+  if (mask && mask[pt] == 0.f) { if (lane == 0) rowloss[pt] = 0.f; return; }
+  const long long n2 = pt / g.L; const int l = (int)(pt - n2 * g.L);
+  const unsigned* pr = reinterpret_cast<const unsigned*>(pred + (n2 * (g.L + 1) + 1 + l) * ldp) + lane;
+  unsigned pv[NP];
+#pragma unroll
+  for (int it = 0; it < NP; ++it) pv[it] = pr[64 * it];
+  float t[2 * NP];
+  patch_load_pairs<C, P_, NP>(g, patch_img(g, img0, img1, n2), l, lane, t);
+  float mu, rs;
+  if (norm_pix) patch_normalise<2 * NP>(g.P, t, mu, rs);
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    s += elem_loss(kind, __uint_as_float(pv[it] << 16), t[2 * it]);
+    s += elem_loss(kind, __uint_as_float(pv[it] & 0xffff0000u), t[2 * it + 1]);
+  }
+  s = wave_sum(s);
+  if (lane == 0) rowloss[pt] = mean_over_last(kind) ? s / g.P : s;
+}
+template <int C, int P_, int NP>
+__global__ __launch_bounds__(256) void recon_bwd_fast_kernel(PatchGeom g, int kind, int norm_pix, long long rows, const float* __restrict__ img0,
+                                                             const float* __restrict__ img1, const bf16_t* __restrict__ pred, long long ldp,
+                                                             const float* __restrict__ mask, const float* __restrict__ losses,
+                                                             const float* __restrict__ gout, float vscale, bf16_t* __restrict__ dpred, long long ldd) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // row of [B2*(L+1)]
+  if (row >= rows) return;
+  const long long n2 = row / (g.L + 1); const int j = (int)(row - n2 * (g.L + 1));
+  unsigned* dp = reinterpret_cast<unsigned*>(dpred + row * ldd) + lane;   // (ldd == P here: no pad columns)
+  const float m = j > 0 ? mask[n2 * g.L + j - 1] : 0.f;
+  if (m == 0.f) {
+#pragma unroll
+    for (int it = 0; it < NP; ++it) dp[64 * it] = 0u;
+    return;
+  }
+  const int l = j - 1, v = (int)(n2 / g.N);
+  const unsigned* pr = reinterpret_cast<const unsigned*>(pred + row * ldp) + lane;
+  unsigned pv[NP];
+#pragma unroll
+  for (int it = 0; it < NP; ++it) pv[it] = pr[64 * it];
+  float t[2 * NP];
+  patch_load_pairs<C, P_, NP>(g, patch_img(g, img0, img1, n2), l, lane, t);
+  float mu, rs;
+  if (norm_pix) patch_normalise<2 * NP>(g.P, t, mu, rs);
+  const float coef = gout[0] * vscale * m / losses[6 + v] / (mean_over_last(kind) ? (float)g.P : 1.f);
+#pragma unroll
+  for (int it = 0; it < NP; ++it)
+    dp[64 * it] = pack2bf(coef * elem_grad(kind, __uint_as_float(pv[it] << 16), t[2 * it]), coef * elem_grad(kind, __uint_as_float(pv[it] & 0xffff0000u), t[2 * it + 1]));
+}
+static bool recon_fast_geometry(int kind, int C, int p, long long ldp, long long ldd) {
+  return kind >= LOSS_MSE && kind <= LOSS_L1 && p == 16 && (C == 3 || C == 4) && ldp % 2 == 0 && ldd == (long long)C * p * p;
 }
 
 static PatchGeom make_geom(int N, int C, int S, int p) {
@@ -152,26 +246,41 @@ extern "C" int csmae_target_minmax(int norm_pix, long long B2, int N, int C, int
   hipLaunchKernelGGL(minmax_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long long)N * g.L, (int)(B2 / N), scratch, out);
   return csmae_check_launch("csmae_target_minmax");
 }
-extern "C" int csmae_recon_loss_fwd(int kind, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
-                                    const float* pred, long long ldp, const float* minmax, float* rowloss, void* stream) {
+extern "C" int csmae_recon_loss_fwd(int kind, int norm_pix, int pred_dtype, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
+                                    const void* pred, long long ldp, const float* minmax, const float* mask, float* rowloss, void* stream) {
   CSMAE_REQUIRE(kind >= LOSS_MSE && kind <= LOSS_BCE, "csmae_recon_loss_fwd: loss kind %d is outside the hot-path scope (ssim family: SURVEY §2 row 2)", kind);
   CSMAE_REQUIRE(B2 > 0 && N > 0 && B2 % N == 0 && S % p == 0 && (kind != LOSS_BCE || minmax), "csmae_recon_loss_fwd: bad args");
+  CSMAE_REQUIRE(pred_dtype == CSMAE_F32 || pred_dtype == CSMAE_BF16, "csmae_recon_loss_fwd: bad prediction dtype %d", pred_dtype);
   PatchGeom g = make_geom(N, C, S, p);
   long long patches = B2 * g.L;
-  hipLaunchKernelGGL(recon_fwd_kernel, dim3(cdiv(patches, 4)), dim3(256), 0, (hipStream_t)stream, g, kind, norm_pix, patches, img0, img1, pred, ldp, minmax, rowloss);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(cdiv(patches, 4)), block(256);
+  if (pred_dtype == CSMAE_BF16 && recon_fast_geometry(kind, C, p, ldp, g.P)) {
+    if (C == 3) hipLaunchKernelGGL((recon_fwd_fast_kernel<3, 16, 6>), grid, block, 0, st, g, kind, norm_pix, patches, img0, img1, (const bf16_t*)pred, ldp, mask, rowloss);
+    else hipLaunchKernelGGL((recon_fwd_fast_kernel<4, 16, 8>), grid, block, 0, st, g, kind, norm_pix, patches, img0, img1, (const bf16_t*)pred, ldp, mask, rowloss);
+  } else if (pred_dtype == CSMAE_BF16) hipLaunchKernelGGL((recon_fwd_kernel<bf16_t>), grid, block, 0, st, g, kind, norm_pix, patches, img0, img1, (const bf16_t*)pred, ldp, minmax, mask, rowloss);
+  else hipLaunchKernelGGL((recon_fwd_kernel<float>), grid, block, 0, st, g, kind, norm_pix, patches, img0, img1, (const float*)pred, ldp, minmax, mask, rowloss);
   return csmae_check_launch("csmae_recon_loss_fwd");
 }
-extern "C" int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, long long B2, int N, int C, int S, int p, const float* img0,
-                                    const float* img1, const float* pred, long long ldp, const float* minmax, const float* mask,
+extern "C" int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, int pred_dtype, long long B2, int N, int C, int S, int p, const float* img0,
+                                    const float* img1, const void* pred, long long ldp, const float* minmax, const float* mask,
                                     const float* losses, const float* gout, float vscale, const float* extra, void* dpred, long long ldd,
                                     void* stream) {
   CSMAE_REQUIRE(kind >= LOSS_MSE && kind <= LOSS_NONE && (kind != LOSS_NONE || extra), "csmae_recon_loss_bwd: bad loss kind %d", kind);
+  CSMAE_REQUIRE((out_dtype == CSMAE_F32 || out_dtype == CSMAE_BF16) && (pred_dtype == CSMAE_F32 || pred_dtype == CSMAE_BF16), "csmae_recon_loss_bwd: bad dtype %d / %d", out_dtype, pred_dtype);
   PatchGeom g = make_geom(N, C, S, p);
   long long rows = B2 * (g.L + 1);
   hipStream_t st = (hipStream_t)stream;
-  if (out_dtype == CSMAE_BF16) hipLaunchKernelGGL((recon_bwd_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, st, g, kind, norm_pix, rows, img0, img1, pred, ldp, minmax, mask, losses, gout, vscale, extra, (bf16_t*)dpred, ldd);
-  else if (out_dtype == CSMAE_F32) hipLaunchKernelGGL((recon_bwd_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, g, kind, norm_pix, rows, img0, img1, pred, ldp, minmax, mask, losses, gout, vscale, extra, (float*)dpred, ldd);
-  else { csmae_set_error("csmae_recon_loss_bwd: bad dtype %d", out_dtype); return CSMAE_ERR_UNSUPPORTED; }
+  const dim3 grid(cdiv(rows, 4)), block(256);
+#define RECON_BWD(T, TP) hipLaunchKernelGGL((recon_bwd_kernel<T, TP>), grid, block, 0, st, g, kind, norm_pix, rows, img0, img1, (const TP*)pred, ldp, minmax, mask, losses, gout, vscale, extra, (T*)dpred, ldd)
+  if (out_dtype == CSMAE_BF16 && pred_dtype == CSMAE_BF16 && !extra && recon_fast_geometry(kind, C, p, ldp, ldd)) {
+    if (C == 3) hipLaunchKernelGGL((recon_bwd_fast_kernel<3, 16, 6>), grid, block, 0, st, g, kind, norm_pix, rows, img0, img1, (const bf16_t*)pred, ldp, mask, losses, gout, vscale, (bf16_t*)dpred, ldd);
+    else hipLaunchKernelGGL((recon_bwd_fast_kernel<4, 16, 8>), grid, block, 0, st, g, kind, norm_pix, rows, img0, img1, (const bf16_t*)pred, ldp, mask, losses, gout, vscale, (bf16_t*)dpred, ldd);
+  } else if (out_dtype == CSMAE_BF16 && pred_dtype == CSMAE_BF16) RECON_BWD(bf16_t, bf16_t);
+  else if (out_dtype == CSMAE_BF16) RECON_BWD(bf16_t, float);
+  else if (pred_dtype == CSMAE_BF16) RECON_BWD(float, bf16_t);
+  else RECON_BWD(float, float);
+#undef RECON_BWD
   return csmae_check_launch("csmae_recon_loss_bwd");
 }
 
@@ -185,12 +294,19 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(int kind, long long rows,
   __shared__ float red[32];
   const int dv = D >> 2;
   float s = 0.f;
-  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
-    const float* pa = a + vrow(va, r) * D; const float* pt = t + vrow(vt, r) * D;
-    for (int c = threadIdx.x; c < dv; c += blockDim.x) {
-      f4_t x = *reinterpret_cast<const f4_t*>(pa + c * 4), y = *reinterpret_cast<const f4_t*>(pt + c * 4);
-      for (int k = 0; k < 4; ++k) s += elem_loss(kind, x[k], y[k]);
+  // items = (row, 16-byte column) pairs, grid-strided: every thread has work whatever the row length (a 512-wide row is 128 items: half of a
+  // workgroup idled when a workgroup walked one row at a time), two items per trip so that four loads are in flight
+  const long long items = rows * dv, step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += 2 * step) {
+    const long long r0 = i / dv, i1 = i + step;
+    const int c0 = (int)(i - r0 * dv);
+    f4_t x0 = *reinterpret_cast<const f4_t*>(a + vrow(va, r0) * D + c0 * 4), y0 = *reinterpret_cast<const f4_t*>(t + vrow(vt, r0) * D + c0 * 4);
+    if (i1 < items) {
+      const long long r1 = i1 / dv; const int c1 = (int)(i1 - r1 * dv);
+      f4_t x1 = *reinterpret_cast<const f4_t*>(a + vrow(va, r1) * D + c1 * 4), y1 = *reinterpret_cast<const f4_t*>(t + vrow(vt, r1) * D + c1 * 4);
+      for (int k = 0; k < 4; ++k) s += elem_loss(kind, x1[k], y1[k]);
     }
+    for (int k = 0; k < 4; ++k) s += elem_loss(kind, x0[k], y0[k]);
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -250,6 +366,38 @@ __global__ __launch_bounds__(256) void ntx_pool_kernel(int Te, int keep, int D, 
   for (int d = threadIdx.x; d < D; d += blockDim.x) z[i * D + d] *= inv;
   if (threadIdx.x == 0) inv_norm[i] = inv;
 }
+// The same for D % 4 == 0, D <= 4096 (every geometry of the step): the sample's keep x D values are walked by ALL 1024 threads — G = 1024 / (D / 4)
+// groups of rows, a thread owns one 16-byte column of every G-th row, its loads independent of each other — and folded through LDS in group
+// order (deterministic).  The first form gave a thread a whole column: `keep` dependent 4-byte loads, 256 threads per sample (0.65 TB/s).
+__global__ __launch_bounds__(1024) void ntx_pool4_kernel(int Te, int keep, int D, const float* __restrict__ latent, float* __restrict__ z, float* __restrict__ inv_norm) {
+  __shared__ float red[32];
+  __shared__ f4_t part[1024];
+  const long long i = blockIdx.x;
+  const int dv = D >> 2, G = 1024 / dv, g = threadIdx.x / dv, c = threadIdx.x - g * dv;
+  f4_t s = {0.f, 0.f, 0.f, 0.f};
+  if (g < G) {
+    const float* base = latent + (i * Te + 1) * D + c * 4;
+    int t = g;
+    for (; t + 3 * G < keep; t += 4 * G) {
+      const f4_t a0 = *reinterpret_cast<const f4_t*>(base + (long long)t * D), a1 = *reinterpret_cast<const f4_t*>(base + (long long)(t + G) * D);
+      const f4_t a2 = *reinterpret_cast<const f4_t*>(base + (long long)(t + 2 * G) * D), a3 = *reinterpret_cast<const f4_t*>(base + (long long)(t + 3 * G) * D);
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; t < keep; t += G) s += *reinterpret_cast<const f4_t*>(base + (long long)t * D);
+    part[threadIdx.x] = s;
+  }
+  __syncthreads();
+  float q = 0.f;
+  if (g == 0) {
+    for (int k = 1; k < G; ++k) s += part[k * dv + c];
+    s = s / (float)keep;
+    q = s[0] * s[0] + s[1] * s[1] + s[2] * s[2] + s[3] * s[3];
+  }
+  q = block_sum(q, red);
+  const float inv = 1.f / fmaxf(sqrtf(q), 1e-12f);
+  if (g == 0) *reinterpret_cast<f4_t*>(z + i * D + c * 4) = s * inv;
+  if (threadIdx.x == 0) inv_norm[i] = inv;
+}
 __global__ __launch_bounds__(1024) void ntx_sim_kernel(int N, int D, const float* __restrict__ z, float tau, float eps, float* __restrict__ E,
                                                       float* __restrict__ neg, float* __restrict__ rowloss) {
   __shared__ float red[32];
@@ -258,13 +406,25 @@ __global__ __launch_bounds__(1024) void ntx_sim_kernel(int N, int D, const float
   for (int d = threadIdx.x; d < D; d += blockDim.x) zi[d] = z[(long long)i * D + d];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool vec = (D & 3) == 0;
   float nsum = 0.f;
   for (int j0 = 4 * w; j0 < B2; j0 += 4 * (blockDim.x >> 6)) {  // four rows per wave iteration: independent load chains, one pass over z_i
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int d = lane; d < D; d += 64) {
-      const float a = zi[d];
+    if (vec) {   // 16-byte loads: D / 256 trips with four rows' loads in flight (scalar loads made this a 12-trip dependent walk at D = 768)
+      for (int d = lane * 4; d < D; d += 256) {
+        const f4_t a = *reinterpret_cast<const f4_t*>(zi + d);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (j0 + u < B2) s[u] += a * z[(long long)(j0 + u) * D + d];
+        for (int u = 0; u < 4; ++u) if (j0 + u < B2) {
+          const f4_t b = *reinterpret_cast<const f4_t*>(z + (long long)(j0 + u) * D + d);
+          s[u] += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+        }
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) {
+        const float a = zi[d];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (j0 + u < B2) s[u] += a * z[(long long)(j0 + u) * D + d];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -315,7 +475,8 @@ extern "C" int csmae_ntxent_fwd(int N, int Te, int keep, int D, const float* lat
                                 float* E, float* neg, float* rowloss, void* stream) {
   CSMAE_REQUIRE(N > 0 && keep > 0 && keep < Te && D > 0 && D * 4 <= 64 * 1024, "csmae_ntxent_fwd: bad geometry N=%d Te=%d keep=%d D=%d", N, Te, keep, D);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ntx_pool_kernel, dim3(2 * N), dim3(256), 0, st, Te, keep, D, latent, z, inv_norm);
+  if (D % 4 == 0 && D <= 4096) hipLaunchKernelGGL(ntx_pool4_kernel, dim3(2 * N), dim3(1024), 0, st, Te, keep, D, latent, z, inv_norm);
+  else hipLaunchKernelGGL(ntx_pool_kernel, dim3(2 * N), dim3(256), 0, st, Te, keep, D, latent, z, inv_norm);
   hipLaunchKernelGGL(ntx_sim_kernel, dim3(2 * N), dim3(1024), D * sizeof(float), st, N, D, z, tau, eps, E, neg, rowloss);
   return csmae_check_launch("csmae_ntxent_fwd");
 }
@@ -841,25 +1002,48 @@ extern "C" int csmae_ssim_bwd(int levels, long long B2, int N, int C, int S, int
 
 // ------------------------------------------------------------------------------------------ scalar assembly
 // losses[0]=total [1]=recon orig [2]=recon crop [3]=cross-decoder [4]=contrastive [5]=latent [6]=sum(mask) orig [7]=sum(mask) crop
+// One pass over everything with independent accumulators and 16-byte loads, ONE seven-value block reduction (the first form walked the two
+// views one after the other with a dependent scalar chain each and ran seven block reductions of three barriers: 29 us on the critical path
+// between forward and backward).  Fixed thread-to-element assignment and fold order: deterministic.
 __global__ __launch_bounds__(1024) void finalize_kernel(long long per_view, int views, const float* __restrict__ rowloss, const float* __restrict__ mask,
                                                        float recon_scale, const float* __restrict__ cd_partial, float cd_scale,
                                                        const float* __restrict__ e_partial, float e_scale, const float* __restrict__ ce_rowloss,
                                                        int ce_rows, float* __restrict__ losses) {
-  __shared__ float red[32];
-  float total = 0.f;
-  for (int v = 0; v < 2; ++v) {
-    float num = 0.f, den = 0.f;
-    if (v < views) for (long long i = threadIdx.x; i < per_view; i += blockDim.x) { float m = mask[v * per_view + i]; num += rowloss[v * per_view + i] * m; den += m; }
-    num = block_sum(num, red); den = block_sum(den, red);
-    float lv = v < views ? num / den : 0.f;  // mask_ratio = 0 -> 0/0 = NaN, as in the reference (MAE_ViT_Shared.py:119)
-    if (threadIdx.x == 0) { losses[1 + v] = lv; losses[6 + v] = den; }
-    total += lv * recon_scale;
+  __shared__ float red[16][8];
+  float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // num0, den0, num1, den1, cd, e, ce
+  const long long total = per_view * views;
+  if ((per_view & 3) == 0) {
+    for (long long i = (long long)threadIdx.x * 4; i < total; i += 4096) {
+      const f4_t r = *reinterpret_cast<const f4_t*>(rowloss + i), m = *reinterpret_cast<const f4_t*>(mask + i);
+      const float num = (r[0] * m[0] + r[1] * m[1]) + (r[2] * m[2] + r[3] * m[3]), den = (m[0] + m[1]) + (m[2] + m[3]);
+      if (i < per_view) { v[0] += num; v[1] += den; } else { v[2] += num; v[3] += den; }
+    }
+  } else {
+    for (long long i = threadIdx.x; i < total; i += 1024) {
+      const float m = mask[i], num = rowloss[i] * m;
+      if (i < per_view) { v[0] += num; v[1] += m; } else { v[2] += num; v[3] += m; }
+    }
   }
-  float cd = 0.f, e = 0.f, ce = 0.f;
-  if (cd_partial) { float s = 0.f; for (int i = threadIdx.x; i < PAIR_BLOCKS; i += blockDim.x) s += cd_partial[i]; cd = block_sum(s, red) * cd_scale; }
-  if (e_partial) { float s = 0.f; for (int i = threadIdx.x; i < PAIR_BLOCKS; i += blockDim.x) s += e_partial[i]; e = block_sum(s, red) * e_scale; }
-  if (ce_rowloss) { float s = 0.f; for (int i = threadIdx.x; i < ce_rows; i += blockDim.x) s += ce_rowloss[i]; ce = block_sum(s, red) / ce_rows; }
-  if (threadIdx.x == 0) { losses[3] = cd; losses[4] = ce; losses[5] = e; losses[0] = total + cd + ce + e; }
+  if (cd_partial) for (int i = threadIdx.x; i < PAIR_BLOCKS; i += 1024) v[4] += cd_partial[i];
+  if (e_partial) for (int i = threadIdx.x; i < PAIR_BLOCKS; i += 1024) v[5] += e_partial[i];
+  if (ce_rowloss) for (int i = threadIdx.x; i < ce_rows; i += 1024) v[6] += ce_rowloss[i];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) v[k] = wave_sum(v[k]);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[7];
+    for (int k = 0; k < 7; ++k) { float a = 0.f; for (int w = 0; w < 16; ++w) a += red[w][k]; t[k] = a; }
+    const float l0 = t[0] / t[1];                              // mask_ratio = 0 -> 0/0 = NaN, as in the reference (MAE_ViT_Shared.py:119)
+    const float l1 = views > 1 ? t[2] / t[3] : 0.f;
+    const float cd = cd_partial ? t[4] * cd_scale : 0.f, e = e_partial ? t[5] * e_scale : 0.f, ce = ce_rowloss ? t[6] / ce_rows : 0.f;
+    losses[1] = l0; losses[2] = l1; losses[6] = t[1]; losses[7] = views > 1 ? t[3] : 0.f;
+    losses[3] = cd; losses[4] = ce; losses[5] = e;
+    losses[0] = (l0 * recon_scale + l1 * recon_scale) + cd + ce + e;
+  }
 }
 extern "C" int csmae_loss_finalize(long long per_view, int views, const float* rowloss, const float* mask, float recon_scale,
                                    const float* cd_partial, float cd_scale, const float* e_partial, float e_scale,

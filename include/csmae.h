@@ -177,13 +177,15 @@ int csmae_rows_scatter_add(int dtype, long long rows, int D, const void* src, fl
 int csmae_rows_gather_idx(long long N, int L, int keep, int D, const float* x, const int* ids, long long ids_ld, float* out, void* stream);
 
 /* ---- MAE_ViT_Shared.forward_loss (:269-290) with process_target/patchify fused (:24-39,97-111).
- * pred is [B2*(L+1), ldp] (row 0 of every sample = cls, ignored); rowloss [B2*L]. */
+ * pred is [B2*(L+1), ldp] (row 0 of every sample = cls, ignored) in `pred_dtype` (fp32, or the bf16 the throughput path's decoder_pred
+ * product writes — what autocast hands the reference's loss); rowloss [B2*L].  fwd: `mask` (nullable, [B2*L]) lets the kernel skip the
+ * patches the loss does not weigh (:113-120): their rowloss is 0. */
 int csmae_target_minmax(int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
                         float* scratch, float* out, void* stream);
-int csmae_recon_loss_fwd(int kind, int norm_pix, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
-                         const float* pred, long long ldp, const float* minmax, float* rowloss, void* stream);
-int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, long long B2, int N, int C, int S, int p, const float* img0,
-                         const float* img1, const float* pred, long long ldp, const float* minmax, const float* mask,
+int csmae_recon_loss_fwd(int kind, int norm_pix, int pred_dtype, long long B2, int N, int C, int S, int p, const float* img0, const float* img1,
+                         const void* pred, long long ldp, const float* minmax, const float* mask, float* rowloss, void* stream);
+int csmae_recon_loss_bwd(int kind, int norm_pix, int out_dtype, int pred_dtype, long long B2, int N, int C, int S, int p, const float* img0,
+                         const float* img1, const void* pred, long long ldp, const float* minmax, const float* mask,
                          const float* losses, const float* gout, float vscale, const float* extra, void* dpred, long long ldd,
                          void* stream);
 /* ---- the ssim family of reconstruction losses: MAE_ViT_Shared.forward_loss_{ssim,ms_ssim} (:165-247) around

@@ -792,6 +792,25 @@ def test_bnrelu_token_axis(ops, dtype, geom):
 
 
 # ------------------------------------------------------------------------------------------------ token plumbing
+@pytest.mark.parametrize("D", [7, 64, 768])
+def test_random_masking_helper_gathers_through_hip(ops, D):
+    """MAE_ViT_Shared.py:57-84 as a stand-alone helper: kept rows == torch.gather over the kernel's own ids (the noise is drawn inside)."""
+    import models_mae
+    m = models_mae.MAE_ViT_Baseline(dim_model=64, encoder_num_layers=1, encoder_num_heads=2, decoder_embed_dim=32, decoder_num_layers=1,
+                                    decoder_num_heads=2, input_size=64, patch_size="16")
+    x = rnd(5, 49, D, seed=71).cuda()
+    for mr in (0.75, 0.1, 0.99):
+        keep = int(49 * (1 - mr))
+        xm, mask, ids_restore = m.random_masking(x, mr)
+        assert xm.shape == (5, keep, D) and mask.shape == (5, 49) and ids_restore.dtype == torch.long
+        ids_keep = torch.argsort(ids_restore, dim=1)[:, :keep]          # inverse permutation = the shuffle order
+        assert torch.equal(xm, torch.gather(x, 1, ids_keep.unsqueeze(-1).expand(-1, -1, D)))
+        assert torch.equal(mask.sum(1), torch.full((5,), 49.0 - keep, device="cuda"))
+    ids = torch.randint(0, 49, (5, 12), dtype=torch.int32, device="cuda")
+    out = ops.rows_gather_idx(x, ids, 9, torch.empty(5, 9, D, device="cuda"))
+    assert torch.equal(out, torch.gather(x, 1, ids[:, :9].long().unsqueeze(-1).expand(-1, -1, D)))
+
+
 @pytest.mark.parametrize("L", [16, 196, 256])
 @pytest.mark.parametrize("mr", [0.75, 0.5])
 def test_mask_sort_bit_exact_vs_reference(ops, L, mr):
@@ -934,6 +953,59 @@ def test_recon_loss_fwd_bwd(ops, kind, norm_pix):
     dpred = torch.full((B2 * (L + 1), P), float("nan"), device="cuda")
     ops.recon_loss_bwd(kind, norm_pix, dev(img0), dev(img1), gp, mm, dev(mask), losses, gout, 1.0, dpred, B2, N, C, S, p)
     assert_close(dpred, pr.grad, 1e-4, 1e-7, f"dpred {kind}")
+    # patches the loss does not weigh may be skipped: same terms, their rowloss is 0
+    rl2 = torch.full((B2 * L,), float("nan"), device="cuda")
+    ops.recon_loss_fwd(kind, norm_pix, dev(img0), dev(img1), gp, mm, rl2, B2, N, C, S, p, mask=dev(mask))
+    assert torch.equal(rl2 * dev(mask).reshape(-1), rowloss * dev(mask).reshape(-1)) and float((rl2 * (1 - dev(mask).reshape(-1))).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kind", ["mse", "l2", "mae", "l1", "bce"])
+@pytest.mark.parametrize("norm_pix", [False, True])
+@pytest.mark.parametrize("C", [3, 4, 5])
+def test_recon_loss_bf16_predictions(ops, kind, norm_pix, C):
+    """Throughput mode: decoder_pred writes bf16, dpred is bf16.  C = 3 / 4 with 16-pixel patches take the pair-per-lane kernels (mse / l2 /
+    mae / l1), everything else the generic ones on bf16 rows — against the oracle on the SAME (bf16-rounded) predictions, and against the
+    generic fp32-input kernels."""
+    import csmae_oracle as O
+    N, S, p = 3, 48, 16
+    L, P = 9, 256 * C
+    B2 = 2 * N
+    img0, img1 = rnd(N, C, S, S, seed=80), rnd(N, C, S, S, seed=81)
+    pred16 = rnd(B2 * (L + 1), P, seed=82).to(torch.bfloat16)
+    pred_full = pred16.float()
+    mask = (torch.rand(B2, L, generator=torch.Generator().manual_seed(83)) > 0.3).float()
+    mask[0, 0] = 1.0
+    pr = pred_full.clone().requires_grad_(True)
+    pv = pr.reshape(B2, L + 1, P)[:, 1:]
+    lo = O.loss_fn(kind, O.recon_target(img0, p, C, norm_pix), pv[:N], mask[:N])
+    lc = O.loss_fn(kind, O.recon_target(img1, p, C, norm_pix), pv[N:], mask[N:])
+    g = 1.3
+    ((lo + lc) * g).backward()
+    mm = None
+    if kind == "bce":
+        mm = torch.empty(4, device="cuda")
+        ops.target_minmax(dev(img0), dev(img1), torch.empty(B2 * L * 2, device="cuda"), mm, B2, N, C, S, p, norm_pix)
+    gm = dev(mask)
+    for use_mask in (True, False):
+        rowloss = torch.full((B2 * L,), float("nan"), device="cuda")
+        ops.recon_loss_fwd(kind, norm_pix, dev(img0), dev(img1), dev(pred16), mm, rowloss, B2, N, C, S, p, mask=gm if use_mask else None)
+        losses = torch.zeros(8, device="cuda")
+        ops.loss_finalize(N * L, 2, rowloss, gm, 1.0, losses)
+        assert_close(losses[1:3], torch.stack([lo, lc]), 2e-5, 1e-6, f"recon {kind} bf16 pred")
+    ref_rows = torch.empty(B2 * L, device="cuda")
+    ops.recon_loss_fwd(kind, norm_pix, dev(img0), dev(img1), dev(pred_full), mm, ref_rows, B2, N, C, S, p)
+    assert_close(rowloss, ref_rows, 2e-5, 1e-6, "rowloss vs the fp32-input kernel")
+    gout = torch.tensor([g], device="cuda")
+    dpred = torch.full((B2 * (L + 1), P), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.recon_loss_bwd(kind, norm_pix, dev(img0), dev(img1), dev(pred16), mm, gm, losses, gout, 1.0, dpred, B2, N, C, S, p)
+    want = pr.grad
+    assert torch.isfinite(dpred.float()).all()
+    assert_close(dpred.float(), want, 2 ** -8, 1e-7, f"dpred {kind} bf16")     # (one bf16 rounding of the fp32 value)
+    if kind != "bce":   # the per-view call of the step engine (a chunk is a view: B2 = N = the view's samples, its own image tensor)
+        rl_v = torch.empty(N * L, device="cuda")
+        ops.recon_loss_fwd(kind, norm_pix, dev(img1), None, dev(pred16)[N * (L + 1):], None, rl_v, N, N, C, S, p, mask=gm[N:])
+        ops.recon_loss_fwd(kind, norm_pix, dev(img0), dev(img1), dev(pred16), mm, rowloss, B2, N, C, S, p, mask=gm)
+        assert torch.equal(rl_v, rowloss[N * L:])
 
 
 def _ssim_run(ops, kind, norm_pix, img0, img1, pred_rows, mask, p, g=0.7, vscale=1.0):

@@ -234,6 +234,12 @@ def test_bench_two_ranks_plumbing_on_one_gpu():
     dp = d["data_parallel"]
     assert dp["ranks_seen"] == 2 and dp["weights_checksum_spread"] == 0.0 and dp["grad_payload"] == "fp32" and dp["buckets_per_step"] >= 3
     assert dp["ms_per_step_min"] <= dp["ms_per_step_max"] == d["ms_per_step"] and dp["loss_min"] < dp["loss_max"]
+    # ... and diagnoses itself: the K steps once more without the collectives, per-bucket exchange times from events
+    # on the exchange stream (one entry per bucket, tiling the flat gradient buffer + the gate slot), the RCCL knobs in force
+    assert dp["ms_per_step_without_collectives"] > 0 and abs(dp["exposed_comm_ms"] - (d["ms_per_step"] - dp["ms_per_step_without_collectives"])) < 2e-3
+    assert len(dp["bucket_allreduce"]) == dp["buckets_per_step"] and all(b["ms"] >= 0 and b["elements"] > 0 for b in dp["bucket_allreduce"])
+    assert abs(dp["bucket_allreduce_ms_sum"] - sum(b["ms"] for b in dp["bucket_allreduce"])) < 1e-2
+    assert dp["rccl_env"]["TORCH_NCCL_HIGH_PRIORITY"] == "1"
 
 
 MICRO6 = dict(dim_model=128, encoder_num_layers=2, encoder_num_heads=2, decoder_embed_dim=64, decoder_num_layers=2, decoder_num_heads=2)
@@ -368,6 +374,73 @@ def test_clip_grad_norm_hip_matches_torch():
     m._test_draws = _draws(1)
     norm = misc.NativeScalerWithGradNormCount()(m(x)[0], opt, clip_grad=max_norm, parameters=m.parameters())
     assert abs(float(norm) - float(want_norm)) <= 1e-4 * float(want_norm)
+
+
+def test_clip_grad_norm_with_user_frozen_parameters_stays_on_the_flat_buffer():
+    """util/misc.py:310-318 with part of the model frozen by the user: torch's clip_grad_norm_ norms only the parameters that have a
+    gradient; the engine still writes dW / db of every layer into the flat buffer, so it clears the frozen slots at the end of the
+    reverse pass and the two-kernel HIP path norms the buffer as a whole (no torch fallback)."""
+    from csmae_hip.engine import FlatParams
+    from util import misc
+    m = _cecd()
+    m.compute_dtype = torch.float32
+    frozen = [n for n, _ in m.named_parameters() if n.startswith("encoder.0.") or n in ("decoder_pred.bias", "predictor.0.weight")]
+    for n, p in m.named_parameters():
+        if n in frozen:
+            p.requires_grad_(False)
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).cuda()
+    m._test_draws = _draws(1)
+    m(x)[0].backward()
+    named = dict(m.named_parameters())
+    assert all(named[n].grad is None for n in frozen)
+    flat = FlatParams.owner_of(named["decoder_pred.weight"])
+    for n in frozen:   # the slots the kernels wrote are zero again
+        assert float(flat.grad_views[n].abs().max()) == 0.0, n
+    params = [p for p in m.parameters() if p.grad is not None]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    for r, p in zip(ref, params):
+        r.grad = p.grad.detach().clone()
+    want_norm = torch.nn.utils.clip_grad_norm_(ref, 1e9)
+    called = []
+    orig = torch.nn.utils.clip_grad_norm_
+    torch.nn.utils.clip_grad_norm_ = lambda *a, **k: called.append(1) or orig(*a, **k)
+    try:
+        got = misc.clip_grad_norm_(m.parameters(), None)
+        max_norm = 0.5 * float(want_norm)
+        want = orig(ref, max_norm)
+        got2 = misc.clip_grad_norm_(m.parameters(), max_norm)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig
+    assert not called, "the frozen-parameter case fell back to torch"
+    assert abs(float(got) - float(want_norm)) <= 2e-6 * float(want_norm) and abs(float(got2) - float(want)) <= 2e-6 * float(want)
+    for r, p in zip(ref, params):
+        torch.testing.assert_close(p.grad, r.grad, rtol=2e-6, atol=0)
+    # a subset of the parameters (not the whole model) is still torch's business
+    sub = [named["decoder_pred.weight"]]
+    assert abs(float(misc.clip_grad_norm_(sub, None)) - float(sub[0].grad.norm())) <= 1e-6 * float(sub[0].grad.norm())
+
+
+def test_gradient_clear_on_the_side_stream_is_ordered_against_every_main_stream_writer(monkeypatch):
+    """the flat gradient buffer is cleared on the weight-gradient stream while the reconstruction head's backward runs on the
+    main stream; main-stream writers into the buffer wait for that clear through ONE event.  A writer placed above the wait would race it:
+    the whole buffer must be bit-identical to the run whose clear sits on the main stream (CSMAE_ZERO_MAIN=1), step after step."""
+    from csmae_hip.engine import FlatParams
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).cuda()
+    outs = {}
+    for mode in ("side", "main"):
+        if mode == "main":
+            monkeypatch.setenv("CSMAE_ZERO_MAIN", "1")
+        m = _cecd()
+        m.compute_dtype = torch.bfloat16
+        snaps = []
+        for k in range(3):
+            m._test_draws = _draws(k + 1)
+            m.zero_grad(set_to_none=True)
+            m(x)[0].backward()
+            snaps.append(FlatParams.owner_of(m.decoder_pred.weight).g.clone())
+        outs[mode] = snaps
+    for a, b in zip(outs["side"], outs["main"]):
+        assert torch.equal(a, b)
 
 
 def test_non_finite_loss_never_reaches_the_weights():
