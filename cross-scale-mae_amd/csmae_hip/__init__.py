@@ -30,9 +30,6 @@ _SIGNATURES = {
     "csmae_fp8_quantize": [I, I, I, L, I, P, L, P, L, P, P, P, P],
     "csmae_fp8_weights": [I, P, P, P, P, P, P, P],
     "csmae_gemm_fp8": [I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P, P, P, L, I, P, P, P, P],
-    "csmae_gemm_resid_stats": [L, L, L, P, L, P, L, P, L, P, P, L, P, L, P],
-    "csmae_gemm_lnfold": [L, L, L, P, L, P, L, P, L, P, P, P, L, I, F, P, P, I, P, L, P],
-    "csmae_ln_fold_weights": [I, I, P, P, P, P, P],
     "csmae_gemm_force_tile": [I],
     "csmae_attn_fwd": [I, L, I, I, I, P, P, P, P],
     "csmae_attn_bwd": [I, L, I, I, I, P, P, P, P, P, P],
@@ -47,9 +44,9 @@ _SIGNATURES = {
     "csmae_crop_resize": [L, I, P, P, P, P],
     "csmae_mask_sort": [L, I, I, P, P, P, P, P, P],
     "csmae_patch_gather": [I, L, I, I, I, I, I, P, P, P, P, L, P],
-    "csmae_embed_assemble": [I, L, I, I, P, P, P, P, P, P, P],
+    "csmae_embed_assemble": [I, L, I, I, P, P, P, P, P, P],
     "csmae_embed_assemble_bwd": [I, I, L, I, I, P, P, P, P],
-    "csmae_unshuffle_fwd": [I, L, I, I, I, P, P, P, P, P, P, P],
+    "csmae_unshuffle_fwd": [I, L, I, I, I, P, P, P, P, P, P],
     "csmae_unshuffle_bwd": [I, I, L, I, I, I, P, P, P, P, P],
     "csmae_rows_gather": [I, L, I, P, L, L, L, P, P],
     "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],

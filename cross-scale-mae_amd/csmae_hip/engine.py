@@ -55,7 +55,6 @@ class FlatParams:
         self.w_lp: Optional[torch.Tensor] = None  # bf16 mirror (allocated on demand)
         self.lp_stamp = None   # sum of the parameters' version counters when the mirror was last made consistent (None: stale)
         self.raw_writes = 0    # writes to the masters that move no version counter (FusedAdamW's kernels, broadcasts): bumped by their authors
-        self.ln_fold = None    # LayerNorm-fold operands of the block Linears (Engine._refresh_fold): W diag(gamma) in bf16, c, b + W beta
         self.params = dict(params)
         with torch.no_grad():
             for name, p in params:
@@ -141,17 +140,10 @@ class Workspace:
         self.tok = E(B2 * max(keep, 1), D, **f32)
 
         def stack(nl, M, Dm, H):
-            # LayerNorm fold (Engine.fold): the normalised activations y1 / y2 are never written in the forward pass — the backward pass
-            # re-materialises one layer's at a time for the weight gradients (one scratch buffer each) — and the residual epilogues leave
-            # per-row partial statistics (`sp`: [x | x_mid][column tile][row][sum, sum of squares]) for the product that follows.
-            ny = 1 if eng.fold else nl
-            d = dict(x=E(nl + 1, M, Dm, **rs), xm=E(nl, M, Dm, **rs), y1=E(ny, M, Dm, **lp), y2=E(ny, M, Dm, **lp),
+            d = dict(x=E(nl + 1, M, Dm, **rs), xm=E(nl, M, Dm, **rs), y1=E(nl, M, Dm, **lp), y2=E(nl, M, Dm, **lp),
                      qkv=E(nl, M, 3 * Dm, **lp), o=E(nl, M, Dm, **lp), h=E(nl, M, 4 * Dm, **lp),
                      pre=E(nl, M, 4 * Dm, device=dev, dtype=torch.uint8 if eng.gp_q8 else T),   # gelu'(pre-activation): one byte per element in throughput mode
                      st=E(nl, 4, M, **f32), lse=E(nl, M * H, **f32))
-            if eng.fold:
-                d["sp"] = E(2, (Dm + 255) // 256, M, 2, **f32)
-                d["st_scratch"] = E(2, M, **f32)
             return d
         self.enc = stack(c["Ne"], Me, D, c["He"])
         self.dec = stack(c["Nd"], Md, Dd, c["Hd"])
@@ -250,13 +242,6 @@ class Engine:
         # DESIGN §4).  CSMAE_RESID_FP32=1 keeps the fp32 stream under the bf16 GEMMs (what torch autocast does; A/B aid).
         self.res_dtype = torch.float32 if (self.T == F32 or os.environ.get("CSMAE_RESID_FP32")) else torch.bfloat16
         self.gp_q8 = self.T == BF16 and not os.environ.get("CSMAE_GP_BF16")   # gelu' saved as 8-bit codes (csmae.h CSMAE_EPI_GELU_Q8); env: A/B aid
-        # LayerNorm folded into the products it feeds (norm1 -> attn.qkv, norm2 -> mlp.fc1; include/csmae.h csmae_gemm_lnfold): the bf16
-        # residual stream is the A operand, the statistics come from the epilogue that wrote it.  Built, parity-tested and measured in
-        # round 3 — and NOT the default: in the step the LayerNorm kernels of one view already run under the other view's GEMMs, so
-        # deleting them buys 0.2-0.3 ms of forward while the heavier epilogues and the re-made y1 / y2 of the backward pass cost more
-        # (22.57 ms un-folded, 22.75 folded; 22.9 with y1 / y2 kept by LayerNorm kernels on a third stream instead).  CSMAE_LNFOLD=1 enables it.
-        self.fold = (self.T == BF16 and not self.fp8 and self.res_dtype == torch.bfloat16 and cfg["D"] % 8 == 0 and cfg["Dd"] % 8 == 0
-                     and bool(os.environ.get("CSMAE_LNFOLD")))
         v = cfg["variant"]
         self.views = 1 if v == "Baseline" else 2
         self.has_pred = v in ("MsLdCd", "MsLdLeCd", "MsLdCeCd")
@@ -325,41 +310,6 @@ class Engine:
             P = self.cfg["P"]
             self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
             self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
-
-    def _fold_sites(self):
-        c = self.cfg
-        return [(f"{stk}.{i}.{norm}", f"{stk}.{i}.{lin}") for stk, n in (("encoder", c["Ne"]), ("decoder", c["Nd"])) for i in range(n)
-                for norm, lin in (("norm1", "attn.qkv"), ("norm2", "mlp.fc1"))]
-
-    def _refresh_fold(self):
-        """Operands of the folded LayerNorms: for every (norm, Linear) pair Wg = bf16(W diag(gamma)), c = rowsum(Wg), b' = b + W beta, made from
-        the fp32 masters by ONE launch whenever the masters have changed (every optimizer step: 6 B per weight element, ~0.4 GB for ViT-B;
-        the plain bf16 mirror of these weights stays: the dX products read it)."""
-        if not self.fold:
-            return
-        f = self.flat
-        if f.ln_fold is None:
-            sl = f.slots
-            desc, off_w, off_v, index = [], 0, 0, {}
-            for norm, lin in self._fold_sites():
-                wo, wn, (N, K) = sl[lin + ".weight"]
-                desc.append([wo, sl[lin + ".bias"][0], sl[norm + ".weight"][0], sl[norm + ".bias"][0], N, K, off_w, off_v])
-                index[lin] = (off_w, off_v, N, K)
-                off_w += _round_up(N * K, 8)
-                off_v += _round_up(2 * N, 8)
-            f.ln_fold = dict(desc=torch.tensor(desc, dtype=torch.long, device=self.device), wg=torch.empty(off_w, device=self.device, dtype=torch.bfloat16),
-                          vec=torch.empty(off_v, device=self.device, dtype=torch.float32), index=index, max_rows=max(d[4] for d in desc), stamp=None)
-        fo = f.ln_fold
-        stamp = (f.version_stamp(), f.raw_writes)
-        if fo["stamp"] != stamp:
-            ops.ln_fold_weights(fo["desc"].shape[0], fo["max_rows"], fo["desc"], f.p, fo["wg"], fo["vec"])
-            fo["stamp"] = stamp
-
-    def _folded(self, lin):
-        """(Wg [N, K] bf16, c [N], b' [N]) of a folded Linear (`lin` = 'encoder.3.attn.qkv')."""
-        fo = self.flat.ln_fold
-        ow, ov, N, K = fo["index"][lin]
-        return fo["wg"][ow:ow + N * K].view(N, K), fo["vec"][ov:ov + N], fo["vec"][ov + N:ov + 2 * N]
 
     def _w_pe(self):
         if self.T == BF16 and self.Pp != self.cfg["P"]:
@@ -458,20 +408,11 @@ class Engine:
         want = max(1, 768 // tiles)
         return max(1, min(want, kt // 4 if kt >= 8 else 1))
 
-    def _dw(self, dy, x, name, pre=()):
+    def _dw(self, dy, x, name):
         """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored)."""
-        self._dw_group([(dy, x, name)], pre=pre)
+        self._dw_group([(dy, x, name)])
 
-    def _renorm(self, S, i, pre, which, st):
-        """LayerNorm fold, backward: the normalised activations of block i's norm1 / norm2 (the other operand of the qkv / fc1 weight
-        gradient) were never written by the forward pass; they are re-made here — on the stream of the weight-gradient launch that
-        reads them, i.e. off the main chain — into the stack's one scratch buffer (the launches of that stream run in order)."""
-        P = self.flat.P
-        x = S["x"][i] if which == 1 else S["xm"][i]
-        y = S["y1"][0] if which == 1 else S["y2"][0]
-        ops.layernorm_fwd(x, P(f"{pre}norm{which}.weight"), P(f"{pre}norm{which}.bias"), y, S["st_scratch"][0], S["st_scratch"][1], st=st)
-
-    def _dw_group(self, items, slots=None, pre=(), ready=None):
+    def _dw_group(self, items, slots=None, ready=None):
         """Weight gradients of several Linear layers over the same tokens, [(dy, x, name)], in one launch (csmae_gemm_dw_group: the
         products share the chip, K slices are folded inside the kernel, the result goes straight into the gradient buffer).
 
@@ -487,8 +428,6 @@ class Engine:
                 prods.append((dy[:, : gw2.shape[0]], x[:, : gw2.shape[1]], gw2, self.flat.G(name + ".bias")))
             grp = self._dw_cache[key] = ops.DwGroup(prods, self.ws.dw_ws)
         if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN"):  # per-kernel HIP-event timing (bench.py) measures on the main stream:
-            for S_, i_, pre_, which in pre:
-                self._renorm(S_, i_, pre_, which, self.st)
             grp.launch(256, st=self.st)   # nothing runs beside the launch there, so it gets the whole chip like the other layouts' kernels
             return                        # (the 160-workgroup setting is a co-scheduling choice of the overlapped step, not a kernel property)
         side = self.side
@@ -498,8 +437,6 @@ class Engine:
             ev = self._event()
             ev.record(self.main)
         side.wait_event(ev)
-        for S_, i_, pre_, which in pre:   # (LayerNorm fold) operands this launch reads that the forward pass did not keep
-            self._renorm(S_, i_, pre_, which, side.cuda_stream)
         grp.launch(slots or self._dw_slots, st=side.cuda_stream)
         done = self._event()
         done.record(side)
@@ -554,23 +491,6 @@ class Engine:
         stt = [a[r] for a in S["st"][i]]
         lse = S["lse"][i][b0 * H * T: (b0 + nb) * H * T]
         qkv, o, h, pre_a = S["qkv"][i][r], S["o"][i][r], S["h"][i][r], S["pre"][i][r]
-        if self.fold:
-            # LayerNorm folded into qkv / fc1: no LayerNorm kernel, no y1 / y2.  The statistics of x come from whoever wrote it (the
-            # previous block's fc2 epilogue; embed_assemble / unshuffle for block 0), those of x_mid from this block's proj epilogue.
-            W, nl = self.W, S["x"].shape[0] - 1
-            sp_x, sp_m = S["sp"][0][:, r], S["sp"][1][:, r]
-            px = 1 if i == 0 else sp_x.shape[0]
-            wg, cc, bf = self._folded(pre + "attn.qkv")
-            ops.gemm_lnfold(x_in, wg, qkv, cc, bf, sp_x, px, stt[0], stt[1], st=st)
-            ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, st=st)
-            ops.gemm_resid_stats(o, W(pre + "attn.proj.weight"), x_mid, P(pre + "attn.proj.bias"), x_in, sp_m, st=st)
-            wg, cc, bf = self._folded(pre + "mlp.fc1")
-            ops.gemm_lnfold(x_mid, wg, h, cc, bf, sp_m, sp_m.shape[0], stt[2], stt[3], epilogue=EPI_GELU, aux=pre_a, st=st)
-            if i + 1 < nl:
-                ops.gemm_resid_stats(h, W(pre + "mlp.fc2.weight"), x_out, P(pre + "mlp.fc2.bias"), x_mid, sp_x, st=st)
-            else:   # (nobody folds the stack's output: the encoder's latent is used as it is, the decoder's goes through decoder_norm)
-                ops.gemm(h, W(pre + "mlp.fc2.weight"), x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st)
-            return
         y1, y2 = S["y1"][i][r], S["y2"][i][r]
         ws_q_a = self.ws.q_a if self.fp8 else None
         ln = int(b0 > 0)
@@ -613,9 +533,7 @@ class Engine:
         dqkv = ws.t3[self._tog][: M * 3 * Dm].view(M, 3 * Dm)
         t1 = ws.t1[: M * Dm].view(M, Dm)
         mode = self._dw_mode
-        fold = self.fold
-        y1, y2 = (S["y1"][0], S["y2"][0]) if fold else (S["y1"][i], S["y2"][i])
-        re1, re2 = (((S, i, pre, 1),), ((S, i, pre, 2),)) if fold else ((), ())   # (LayerNorm fold) y1 / y2 are re-made in front of the launch that reads them
+        y1, y2 = S["y1"][i], S["y2"][i]
         if mode in ("block_enc", "block_dec"):   # A/B aid: the one-launch form for one of the two stacks only
             mode = "block" if (mode == "block_enc") == (S is ws.enc) else "half"
         if mode == "block":   # (wide models: the block's tiles exceed the launch's workgroups — 192 at ViT-L, 300 at ViT-H — and two launches interleave better with the main chain)
@@ -644,9 +562,9 @@ class Engine:
             self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
         slots = self._dw_slots_ed[0 if S is ws.enc else 1] if self._dw_slots_ed else None
         if mode == "half":
-            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, pre=re2, ready=ev1)
+            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, ready=ev1)
         elif mode == "none":
-            self._dw(dpre, y2, pre + "mlp.fc1", pre=re2)
+            self._dw(dpre, y2, pre + "mlp.fc1")
         self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
         self._guard_write(nxt)
         kn = self._fp8_alloc()
@@ -668,11 +586,11 @@ class Engine:
             ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, emit=eq, st=st)
         if mode == "block":
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1"),
-                            (nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re2 + re1, ready=ev2)
+                            (nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2)
         elif mode == "half":
-            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, pre=re1, ready=ev2)
+            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2)
         else:
-            self._dw(dqkv, y1, pre + "attn.qkv", pre=re1)
+            self._dw(dqkv, y1, pre + "attn.qkv")
         self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st, site=kq, a8=eq[0] if eq else None)
         self._guard_write(out)
         kx = self._fp8_alloc() if i > 0 else None     # the next block's fc2-backward reads `out`
@@ -707,7 +625,6 @@ class Engine:
         self.st = st = ops.stream()
         B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
         self._refresh_lp()
-        self._refresh_fold()
         self._fp8_begin()
         img0 = imgs
         if self.views != 2:
@@ -720,8 +637,7 @@ class Engine:
         ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
         ops.patch_gather(img0, img1, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
         ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
-        ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep,
-                           stats=ws.enc["sp"][0][0] if self.fold else None, st=st)
+        ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep, st=st)
         latent = ws.enc["x"][c["Ne"]]
         lat_heads = ws.lat32 if ws.lat32 is not None else latent   # what the loss heads read (fp32)
         main = torch.cuda.current_stream()
@@ -781,7 +697,7 @@ class Engine:
             evs.append(ev)
             ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z[re_], bias=P("decoder_embed.bias"), st=st)
             ops.unshuffle_fwd(ws.z[re_], P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore[b0:b0 + nb],
-                              ws.dec["x"][0][rd_], nb, L, keep, stats=ws.dec["sp"][0][0][rd_] if self.fold else None, st=st)
+                              ws.dec["x"][0][rd_], nb, L, keep, st=st)
             yield
             for i in range(c["Nd"]):
                 self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, b0, nb, st)
@@ -902,14 +818,12 @@ class Engine:
         self.st = st = ops.stream()
         L, D = c["L"], c["D"]
         self._refresh_lp()
-        self._refresh_fold()
         self._fp8_begin()
         ws.noise.copy_(noise)
         ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
         ops.patch_gather(imgs, None, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
         ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
-        ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], N, keep,
-                           stats=ws.enc["sp"][0][0] if self.fold else None, st=st)
+        ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], N, keep, st=st)
         for i in range(c["Ne"]):
             self._block_fwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], N, ws.Te)
         lat = ws.enc["x"][c["Ne"]]
@@ -931,7 +845,6 @@ class Engine:
         ws, P = self.ws, self.flat.P
         self.st = st = ops.stream()
         self._refresh_lp()
-        self._refresh_fold()
         self._fp8_begin()
         lat = latent.reshape(N * Te, D).to(torch.float32).contiguous()
         if self.T == BF16:
@@ -941,8 +854,7 @@ class Engine:
             lat_op = lat
         ws.ids_restore.copy_(ids_restore)
         ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z, bias=P("decoder_embed.bias"), st=st)
-        ops.unshuffle_fwd(ws.z, P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore, ws.dec["x"][0], N, L, keep,
-                          stats=ws.dec["sp"][0][0] if self.fold else None, st=st)
+        ops.unshuffle_fwd(ws.z, P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore, ws.dec["x"][0], N, L, keep, st=st)
         for i in range(c["Nd"]):
             self._block_fwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], N, ws.Td)
         ops.layernorm_fwd(ws.dec["x"][c["Nd"]], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp, ws.dn_st[0], ws.dn_st[1], y32=ws.emb32, st=st)

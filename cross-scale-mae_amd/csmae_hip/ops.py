@@ -125,48 +125,6 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NON
     return out
 
 
-def gemm_resid_stats(a, b, out, bias, resid, st_part, st=None):
-    """out = a b^T + bias + resid (bf16, the residual stream) like gemm(..., epilogue=EPI_RESID); additionally st_part[tn, m] = (sum, sum of
-    squares) of the row segment of column tile tn (256 columns) — st_part: fp32 [>= ceil(N / 256), M, 2] (a row-range view of a larger
-    [parts, rows, 2] buffer is fine)."""
-    M, K = a.shape
-    N = b.shape[0]
-    assert b.shape[1] == K and out.shape == (M, N) and resid.dtype == out.dtype == torch.bfloat16 and a.dtype == b.dtype == torch.bfloat16
-    assert st_part.dtype == torch.float32 and st_part.shape[0] * 256 >= N and st_part.shape[1] == M and st_part.stride(1) == 2 and st_part.stride(2) == 1
-    if _timer is not None:
-        _timer.begin()
-    check(load().csmae_gemm_resid_stats(M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(bias), _p(resid), resid.stride(0),
-                                        _p(st_part), st_part.stride(0), st if st is not None else stream()), "csmae_gemm_resid_stats")
-    if _timer is not None:
-        _timer.end("gemm_bf16_NT", 2.0 * M * N * K)
-    return out
-
-
-def gemm_lnfold(x, wg, out, c, bias_f, st_part, parts, mean, rstd, eps=1e-6, epilogue=EPI_NONE, aux=None, st=None):
-    """out = LayerNorm(x) W^T + b with the LayerNorm folded into the product: x [M, K] bf16 (the residual stream), wg = bf16(W diag(gamma))
-    [N, K], c[n] = sum_k wg[n, k], bias_f = b + W beta, st_part [>= parts, M, 2] the producer's partial row statistics.  mean / rstd [M]
-    are outputs (the backward pass reads them)."""
-    M, K = x.shape
-    N = wg.shape[0]
-    assert wg.shape[1] == K and out.shape == (M, N) and x.dtype == wg.dtype == out.dtype == torch.bfloat16
-    assert st_part.dtype == torch.float32 and st_part.shape[0] >= parts and st_part.shape[1] == M and st_part.stride(1) == 2 and st_part.stride(2) == 1
-    if aux is not None and aux.dtype == torch.uint8:
-        epilogue = {EPI_GELU: 6}[epilogue]
-    if _timer is not None:
-        _timer.begin()
-    check(load().csmae_gemm_lnfold(M, N, K, _p(x), x.stride(0), _p(wg), wg.stride(0), _p(out), out.stride(0), _p(c), _p(bias_f), _p(st_part),
-                                   st_part.stride(0), parts, eps, _p(mean), _p(rstd), epilogue, _p(aux), aux.stride(0) if aux is not None else 0,
-                                   st if st is not None else stream()), "csmae_gemm_lnfold")
-    if _timer is not None:
-        _timer.end("gemm_bf16_NT", 2.0 * M * N * K)
-    return out
-
-
-def ln_fold_weights(count, max_rows, desc, p, wg, vec, st=None):
-    """Wg = bf16(W diag(gamma)), c = rowsum(Wg), b' = b + W beta for `count` (LayerNorm, Linear) pairs in one launch (desc: int64 [count, 8])."""
-    check(load().csmae_ln_fold_weights(count, max_rows, _p(desc), _p(p), _p(wg), _p(vec), st if st is not None else stream()), "csmae_ln_fold_weights")
-
-
 def gemm_dw(dy, x, dw, workspace, db=None, st=None):
     """dw[out,in] (fp32, contiguous) += dy[tokens,out]^T x[tokens,in] via split-K slabs in `workspace` (fp32); db[out] += colsum(dy)."""
     K, M = dy.shape
@@ -335,9 +293,8 @@ def patch_gather(img0, img1, ids_keep, out, N, C, S, p, keep, st=None):
                                     st if st is not None else stream()), "csmae_patch_gather")
 
 
-def embed_assemble(tok, pos, cls, ids_keep, x, B2, keep, stats=None, st=None):
-    """stats (optional, fp32 [rows, 2]): (sum, sum of squares) of every row written — the LayerNorm statistics gemm_lnfold folds."""
-    check(load().csmae_embed_assemble(dt(x), B2, keep, x.shape[-1], _p(tok), _p(pos), _p(cls), _p(ids_keep), _p(x), _p(stats),
+def embed_assemble(tok, pos, cls, ids_keep, x, B2, keep, st=None):
+    check(load().csmae_embed_assemble(dt(x), B2, keep, x.shape[-1], _p(tok), _p(pos), _p(cls), _p(ids_keep), _p(x),
                                       st if st is not None else stream()), "csmae_embed_assemble")
 
 
@@ -346,8 +303,8 @@ def embed_assemble_bwd(dx, dtok, dcls, B2, keep, st=None):
           "csmae_embed_assemble_bwd")
 
 
-def unshuffle_fwd(z, mask_token, dpos, ids_restore, xd, B2, L, keep, stats=None, st=None):
-    check(load().csmae_unshuffle_fwd(dt(xd), B2, L, keep, xd.shape[-1], _p(z), _p(mask_token), _p(dpos), _p(ids_restore), _p(xd), _p(stats),
+def unshuffle_fwd(z, mask_token, dpos, ids_restore, xd, B2, L, keep, st=None):
+    check(load().csmae_unshuffle_fwd(dt(xd), B2, L, keep, xd.shape[-1], _p(z), _p(mask_token), _p(dpos), _p(ids_restore), _p(xd),
                                      st if st is not None else stream()), "csmae_unshuffle_fwd")
 
 

@@ -49,15 +49,7 @@ struct GemmArgs {
   // scaled with the amax this tensor had one step earlier (q_amax_prev: 64 partial maxima), records the new amax (q_amax_next: 64 slots)
   // and leaves the de-quantisation factor in q_dq — the separate quantisation pass (read 2 B + write 1 B per element) disappears.
   unsigned char* q_out; long long ldq; const float* q_amax_prev; float* q_amax_next; float* q_dq; int q_fmt;
-  // LayerNorm folded into the Linear it feeds (timm Block: norm1 -> attn.qkv, norm2 -> mlp.fc1; csmae_gemm_lnfold below).
-  //  producer side (the residual epilogue that writes the stream x): per row and 256-column tile, (sum, sum of squares) of the values it
-  //    wrote, st_out[tn * st_stride + 2 m] — the statistics pass of LayerNorm without a second read of x;
-  //  consumer side: A = x itself, B = W diag(gamma) (bf16), C = rstd[m] (acc - mean[m] ln_c[n]) + bias[n] with ln_c[n] = sum_k B[n,k] and
-  //    bias = b + W beta, the row statistics folded from the st_parts partials; the tn == 0 tiles leave mean / rstd for the backward pass.
-  // (these travel in a kernel argument of their own, LnArgs, and only to the two instantiations that use them: eight more kernel-argument
-  // words in GemmArgs cost every GEMM launch of the step ~1 %)
 };
-struct LnArgs { float* st_out; const float* st_in; long long st_stride; int st_parts; const float* ln_c; float ln_eps; float* ln_mean; float* ln_rstd; };
 
 // gelu'(x) lies in [-0.129, 1.129]: stored as the 8-bit code q = round(200 g + 26) (range [-0.13, 1.145], step 5e-3, |error| <= 2.5e-3 — the
 // size of a bf16 rounding step at 1) it costs one byte instead of two in the two epilogues that are bound by their HBM bytes (fc1 writes h
@@ -228,87 +220,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& p, void* Cptr, f4_
   }
 }
 
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// sum over the 8 lanes that share a row segment (aligned groups of 8): half-mirror, then the two quad permutations — three DPP adds, no LDS
-__device__ __forceinline__ float sum8(float v) {
-  v += dpp_mov<0x141>(v);   // row_half_mirror: l <-> 7 - l
-  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-  return v;
-}
-
-// Consumer side of the LayerNorm fold: v <- rstd[m] * acc - rstd[m] mean[m] c[n] + bias[n], applied where an epilogue moves a fragment
-// from the accumulators into its LDS strip (updating the 128 accumulator registers in place made the allocator spill: it renames).
-// The row statistics are fetched at the very start of the tile (ln_stats_issue: asm loads, in flight under the DMA prologue, which waits
-// for everything older than its own pieces anyway) and folded to (rstd, -mean rstd) for the lane's two rows right behind the prologue's
-// wait (ln_stats_fold): 4 registers through the main loop instead of two exposed global-memory round trips in front of the epilogue
-// (measured: +11 us on a 52-us launch).  ln_fold_prepare parks them in a wave-private LDS patch `sw` for the fragment rows and loads c and
-// the folded bias of the lane's 4 x FN columns.
-#define LN_MAXP 5   // column tiles of the producer: ceil(D / 256) for D <= 1280
-struct LnStatRegs { f2_t v[2][LN_MAXP]; };
-template <int WM>
-__device__ __forceinline__ void ln_stats_issue(const GemmArgs& p, const LnArgs& ln, LnStatRegs& sr, int lane, int mbase) {
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int gm = min(mbase + min(rr * 64 + lane, WM - 1), p.M - 1);
-#pragma unroll
-    for (int pp = 0; pp < LN_MAXP; ++pp) {   // (parts beyond st_parts re-read the last one and are not summed: no branch, no dynamic register index)
-      const float* ptr = ln.st_in + (long long)min(pp, ln.st_parts - 1) * ln.st_stride + 2ll * gm;
-      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sr.v[rr][pp]) : "v"(ptr) : "memory");
-    }
-  }
-}
-template <int WM>   // call behind a wait that covers the loads of ln_stats_issue; returns (rstd, -mean rstd) of rows lane and 64 + lane of the wave's tile
-__device__ __forceinline__ void ln_stats_fold(const GemmArgs& p, const LnArgs& ln, LnStatRegs& sr, float2 (&st)[2], int lane, int mbase, bool writer) {
-  const float invK = 1.0f / (float)p.K;
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int pp = 0; pp < LN_MAXP; ++pp) {
-      asm volatile("" : "+v"(sr.v[rr][pp]));   // (ordered behind the wait: the compiler knows nothing about the asm loads' latency)
-      if (pp < ln.st_parts) { s += sr.v[rr][pp][0]; q += sr.v[rr][pp][1]; }
-    }
-    const float mean = s * invK, var = fmaxf(q * invK - mean * mean, 0.f), rstd = rsqrtf(var + ln.ln_eps);
-    st[rr] = make_float2(rstd, -mean * rstd);
-    const int r = rr * 64 + lane;
-    if (writer && r < WM && mbase + r < p.M) { ln.ln_mean[mbase + r] = mean; ln.ln_rstd[mbase + r] = rstd; }
-  }
-}
-template <int FN, int FM> struct LnFoldRegs { f4_t c4[FN], b4[FN]; float2 st[FM]; };
-template <int FN, int FM, int WM>
-__device__ __forceinline__ void ln_fold_prepare(const GemmArgs& p, const LnArgs& ln, LnFoldRegs<FN, FM>& lf, const float2 (&st)[2], float* sw, int lane, int t, int g, int nbase) {
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {   // (issued first: their latency runs under the LDS round trip below)
-    const int n = nbase + j * 16 + 4 * g;
-    const bool ok = n < p.N;
-    lf.c4[j] = ok ? *reinterpret_cast<const f4_t*>(ln.ln_c + n) : f4_t{0.f, 0.f, 0.f, 0.f};
-    lf.b4[j] = (ok && p.bias) ? *reinterpret_cast<const f4_t*>(p.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  // lane L holds the statistics of rows L and 64 + L; fragment row i wants row 16 i + (lane & 15): one trip through a wave-private LDS
-  // patch, all FM reads up front (read one by one next to the strip writes they cannot be told apart from, each would wait for the strip)
-  *reinterpret_cast<float2*>(sw + 2 * lane) = st[0];
-  if (64 + lane < WM) *reinterpret_cast<float2*>(sw + 2 * (64 + lane)) = st[1];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) lf.st[i] = *reinterpret_cast<const float2*>(sw + 2 * (i * 16 + t));   // (wave-private: a wave's LDS operations stay in order)
-}
-template <int FN, int FM>   // fragment (fragment row i of the wave's tile, column fragment j) on its way to the strip
-__device__ __forceinline__ f4_t ln_fold_frag(const LnFoldRegs<FN, FM>& lf, f4_t a, int i, int j) {
-  const float2 st = lf.st[i];
-  f4_t o;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = fmaf(a[r], st.x, fmaf(st.y, lf.c4[j][r], lf.b4[j][r]));
-  return o;
-}
-
 // bf16 outputs, 8 columns per lane: 16-byte stores (one instruction covers 8 rows x 128 B instead of 4).  The epilogue of a
 // 256x256 tile is bound by the store ISSUE rate of its CU, not by HBM: halving the number of store instructions is what counts.
-template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR, bool LNF = false>
-__device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g,
-                                                     float* srow = nullptr /* RESID: LDS [WM][2], receives (sum, sum of squares) of this wave's 64 columns per row */,
-                                                     const LnFoldRegs<FN, FM>* lf = nullptr /* LNF: consumer side of the LayerNorm fold */) {
+template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR>
+__device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
   constexpr int LPR = FN * 16 / 8, RPP = 64 / LPR, NPASS = EROWS / RPP, NPART = WM / EROWS;
   constexpr bool NEEDS_LOAD = EPI == EPI_DGELU || EPI == EPI_RESID;
   const int col = (lane % LPR) * 8, rsub = lane / LPR;
@@ -358,9 +273,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
     for (int ii = 0; ii < EROWS / 16; ++ii)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        f4_t v = acc[part * (EROWS / 16) + ii][j];
-        if (LNF) v = ln_fold_frag<FN, FM>(*lf, v, part * (EROWS / 16) + ii, j);
-        *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = v;
+        *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = acc[part * (EROWS / 16) + ii][j];
       }
     if (NEEDS_LOAD && part + 1 < NPART) load_part(part + 1, ld[(part + 1) & 1]);
 #pragma unroll
@@ -379,14 +292,6 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
         f4_t a1 = f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
         if (EPI == EPI_DGELU && p.aux_q8) { a0 = gp_q8_unpack4(a.x); a1 = gp_q8_unpack4(a.y); }
         if (EPI == EPI_DGELU) { o0 = v0 * a0; o1 = v1 * a1; } else { o0 = v0 + a0; o1 = v1 + a1; }
-      }
-      if (EPI == EPI_RESID && srow != nullptr) {   // row statistics of the stream this epilogue writes (columns beyond N and rows beyond M hold zeros):
-        // of the ROUNDED values — the consumer subtracts mean * c from a product over exactly these bf16 numbers (statistics of the fp32
-        // values would be off by the row's mean rounding error, ~2e-4 relative, which c[n] carries into every output of the row)
-        const f4_t r0 = round4<bf16_t>(o0), r1 = round4<bf16_t>(o1);
-        const float s = sum8(((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3])));
-        const float q = sum8(fmaf(r0[0], r0[0], fmaf(r0[1], r0[1], fmaf(r0[2], r0[2], r0[3] * r0[3]))) + fmaf(r1[0], r1[0], fmaf(r1[1], r1[1], fmaf(r1[2], r1[2], r1[3] * r1[3]))));
-        if ((lane % LPR) == 0) *reinterpret_cast<float2*>(srow + 2 * (part * EROWS + ps * RPP + rsub)) = make_float2(s, q);
       }
       if (emit && gm < p.M && ok0) {   // the fp8 copy of this row segment (8 or 4 columns)
         f4_t q0 = o0 * qscale, q1 = o1 * qscale;
@@ -459,9 +364,8 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
 // 32-bit add per pass, rows beyond M are dropped by the hardware's range check, columns beyond N are marked out of range once per tile.
 // Requirements (checked by the caller): N % 8 == 0 (a lane's 8 columns are valid or not as a whole), (M + 256) rows of every tensor < 4 GiB,
 // no fused fp8 copy.  Same arithmetic, same bytes as epilogue_rows_bf16x8.
-template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR, bool LNF = false>
-__device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g,
-                                                      float* srow = nullptr, const LnFoldRegs<FN, FM>* lf = nullptr) {
+template <int EPI, int FM, int FN, int WM, int EROWS, int ESTR>
+__device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&acc)[FM][FN], float* ew, int mbase, int nbase, int lane, int t, int g) {
   constexpr int LPR = FN * 16 / 8, RPP = 64 / LPR, NPASS = EROWS / RPP, NPART = WM / EROWS;
   constexpr bool NEEDS_LOAD = EPI == EPI_DGELU || EPI == EPI_RESID;
   const int col = (lane % LPR) * 8, rsub = lane / LPR;
@@ -503,9 +407,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&
     for (int ii = 0; ii < EROWS / 16; ++ii)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        f4_t v = acc[part * (EROWS / 16) + ii][j];
-        if (LNF) v = ln_fold_frag<FN, FM>(*lf, v, part * (EROWS / 16) + ii, j);
-        *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = v;
+        *reinterpret_cast<f4_t*>(ew + (ii * 16 + t) * ESTR + j * 16 + 4 * g) = acc[part * (EROWS / 16) + ii][j];
       }
     if (NEEDS_LOAD && part + 1 < NPART) load_part(ld[(part + 1) & 1]);
 #pragma unroll
@@ -520,12 +422,6 @@ __device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&
         f4_t a1 = f4_t{__uint_as_float(a.z << 16), __uint_as_float(a.z & 0xffff0000u), __uint_as_float(a.w << 16), __uint_as_float(a.w & 0xffff0000u)};
         if (EPI == EPI_DGELU && q8) { a0 = gp_q8_unpack4(a.x); a1 = gp_q8_unpack4(a.y); }
         if (EPI == EPI_DGELU) { o0 = v0 * a0; o1 = v1 * a1; } else { o0 = v0 + a0; o1 = v1 + a1; }
-      }
-      if (EPI == EPI_RESID && srow != nullptr) {   // row statistics of the stream this epilogue writes, of the ROUNDED values (see epilogue_rows_bf16x8)
-        const f4_t r0 = round4<bf16_t>(o0), r1 = round4<bf16_t>(o1);
-        const float s = sum8(((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3])));
-        const float q = sum8(fmaf(r0[0], r0[0], fmaf(r0[1], r0[1], fmaf(r0[2], r0[2], r0[3] * r0[3]))) + fmaf(r1[0], r1[0], fmaf(r1[1], r1[1], fmaf(r1[2], r1[2], r1[3] * r1[3]))));
-        if ((lane % LPR) == 0) *reinterpret_cast<float2*>(srow + 2 * (part * EROWS + ps * RPP + rsub)) = make_float2(s, q);
       }
       if (EPI == EPI_GELU && !(GEMM_EPI_ABL & 2)) {
         if (!q8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]))), rsL, offL, 0, 0);
@@ -558,16 +454,15 @@ __device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&
 // not as fp32.  A 256 x 256 tile's epilogue (7 k clocks at K = 512 .. 768, a quarter of the tile) spent 3.3 k of them pushing 256 KiB
 // of fp32 accumulators through ds_write_b128 (13 clocks per KiB); rounding first halves the bytes written and read and leaves the
 // row-segment pass with nothing to compute.  The arithmetic is unchanged (acc + bias in fp32, one rounding): bit-identical outputs.
-template <int FM, int FN, int WM, bool LNF = false>
-__device__ __forceinline__ void epilogue_rows_bf16_plain(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], char* ew, int mbase, int nbase, int lane, int t, int g,
-                                                         const LnFoldRegs<FN, FM>* lf = nullptr) {
+template <int FM, int FN, int WM>
+__device__ __forceinline__ void epilogue_rows_bf16_plain(const GemmArgs& p, void* Cptr, f4_t (&acc)[FM][FN], char* ew, int mbase, int nbase, int lane, int t, int g) {
   constexpr int WN = FN * 16, ROWB = WN * 2 + 8, EROWS = (WM % 64 == 0) ? 64 : 32, NPART = WM / EROWS, LPR = WN / 8, RPP = 64 / LPR, NPASS = EROWS / RPP;
   static_assert(WM % EROWS == 0 && EROWS * ROWB <= 32 * (WN + 4) * 4, "the bf16 strip reuses the fp32 strip's bytes");
   f4_t bj[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int n = nbase + j * 16 + 4 * g;
-    bj[j] = (!LNF && p.bias && n < p.N) ? *reinterpret_cast<const f4_t*>(p.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
+    bj[j] = (p.bias && n < p.N) ? *reinterpret_cast<const f4_t*>(p.bias + n) : f4_t{0.f, 0.f, 0.f, 0.f};
   }
   const int col = (lane % LPR) * 8, rsub = lane / LPR;
   const int gn = nbase + col;
@@ -582,7 +477,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_plain(const GemmArgs& p, void
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         f4_t v = acc[part * (EROWS / 16) + ii][j];
-        if (LNF) v = ln_fold_frag<FN, FM>(*lf, v, part * (EROWS / 16) + ii, j); else v += bj[j];
+        v += bj[j];
         *reinterpret_cast<uint2*>(ew + (ii * 16 + t) * ROWB + (j * 16 + 4 * g) * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       }
 #pragma unroll
@@ -832,9 +727,8 @@ extern "C" int csmae_debug_gemm_ts(unsigned long long* out) { return (int)hipMem
 // dense 256 x 256 slabs) and its column-sum partials ([nsplit][nslots][256]) when a tile is cut into several slices.
 struct DwFold { float* slab; float* cs_slab; int nsplit; int slot; int nslots; };
 
-template <bool TA, bool TB, int BM, bool GROUP, int LNM = 0>   // LNF: consumer side of the LayerNorm fold (its own instantiation: a run-time branch around 128 accumulator updates made the allocator spill)
-__device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold fold, const LnArgs& ln = LnArgs{}) {
-  constexpr bool LNF = LNM == 1, LNS = LNM == 2;   // LayerNorm fold: consumer side / producer side (row statistics of the stream it writes)
+template <bool TA, bool TB, int BM, bool GROUP>
+__device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold fold) {
   static_assert(BM == 256 || (BM == 192 && !TA), "192-row tiles exist for K-contiguous A only");
   constexpr int BN = 256, WM = BM / 2, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
   constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;  // ring slot = 32 KiB; a B image fills it, a 192-row A image uses 24 KiB
@@ -846,9 +740,6 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   void* Cptr = (!GROUP && p.epi == EPI_SPLIT) ? static_cast<void*>(reinterpret_cast<float*>(p.C) + (long long)split * p.split_stride) : p.C;
 
   GTS(0);
-  LnStatRegs lnsr;
-  float2 lnst[2];
-  if (LNF) ln_stats_issue<BM / 2>(p, ln, lnsr, lane, m0 + (w / 4) * (BM / 2));
   const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   const unsigned kstepA = TA ? (unsigned)(64 * p.lda * 2) : 128u;
   const unsigned kstepB = TB ? (unsigned)(64 * p.ldb * 2) : 128u;
@@ -1001,7 +892,6 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   else if (issued0 == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPA + PPU) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (LNF) ln_stats_fold<BM / 2>(p, ln, lnsr, lnst, lane, m0 + (w / 4) * (BM / 2), tn == 0 && (w % 4) == 0);   // (the loads are older than the prologue's DMA pieces: the wait above covers them)
   GTS(1);
   s8_t fa[FM], fb0[FN], fb1[FN];
   if (USE_ASM) {  // (asm reads carry their destination as "+v": give the registers a defined value once)
@@ -1111,29 +1001,16 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
     return;
   }
   constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
-  constexpr int STRIP = NW * EROWS * ESTR * 4, LNPATCH = NWN * BM * 2 * 4;   // behind the strip: the LayerNorm-fold patches ([wave][WM][2] floats on the consumer side, [NWN][BM][2] on the producer side)
-  static_assert(STRIP + LNPATCH <= NUNIT * UNIT, "epilogue strip must fit the staging ring");
+  constexpr int STRIP = NW * EROWS * ESTR * 4;
+  static_assert(STRIP <= NUNIT * UNIT, "epilogue strip must fit the staging ring");
   // (no barrier: nothing has read or written the ring since the last step's barrier)
   float* ew = reinterpret_cast<float*>(smem) + w * (EROWS * ESTR);
-  float* lnp = reinterpret_cast<float*>(smem + STRIP);
-  if (LNF) {   // consumer side of the LayerNorm fold (csmae_gemm_lnfold: bf16 C, 16-byte rows, plain or GELU epilogue — checked on the host)
-    LnFoldRegs<FN, FM> lf;
-    ln_fold_prepare<FN, FM, WM>(p, ln, lf, lnst, lnp + w * (WM * 2), lane, t, g, n0 + wn);
-    GemmArgs pe = p;
-    pe.bias = nullptr;   // (the bias enters with the fold)
-    if (p.epi == EPI_GELU && (p.a_fmt & 256)) epilogue_rows_bf16x8b<EPI_GELU, FM, FN, WM, EROWS, ESTR, true>(pe, acc, ew, m0 + wm, n0 + wn, lane, t, g, nullptr, &lf);
-    else if (p.epi == EPI_GELU) epilogue_rows_bf16x8<EPI_GELU, FM, FN, WM, EROWS, ESTR, true>(pe, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g, nullptr, &lf);
-    else epilogue_rows_bf16_plain<FM, FN, WM, true>(pe, Cptr, acc, reinterpret_cast<char*>(ew), m0 + wm, n0 + wn, lane, t, g, &lf);
-    GTS(3);
-    return;
-  }
-  float* srow = LNS ? lnp + ((w % NWN) * BM + wm) * 2 : nullptr;
 #define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
-#define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g, srow)
+#define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0 + wm, n0 + wn, lane, t, g)
   const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
                                                                                    : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));  // 16-byte row segments
   if (p.c_dtype == CSMAE_BF16) {
-#define EPI_CALL8B(E_) epilogue_rows_bf16x8b<E_, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g, srow)
+#define EPI_CALL8B(E_) epilogue_rows_bf16x8b<E_, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0 + wm, n0 + wn, lane, t, g)
     if (wide && p.epi == EPI_NONE && p.q_out == nullptr)
       epilogue_rows_bf16_plain<FM, FN, WM>(p, Cptr, acc, reinterpret_cast<char*>(ew), m0 + wm, n0 + wn, lane, t, g);
     else if (wide && (p.a_fmt & 256)) { if (p.epi == EPI_GELU) EPI_CALL8B(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8B(EPI_DGELU); else EPI_CALL8B(EPI_RESID); }   // buffer addressing (bit 8 of a_fmt: set by the host when the sizes allow it)
@@ -1148,15 +1025,6 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   }
 #undef EPI_CALL
 #undef EPI_CALL8
-  if (LNS) {   // fold the four column waves' row statistics: one (sum, sumsq) per row of this tile
-    __syncthreads();
-    if (threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int k = 0; k < NWN; ++k) { const float2 v = *reinterpret_cast<const float2*>(lnp + (k * BM + threadIdx.x) * 2); s += v.x; q += v.y; }
-      *reinterpret_cast<float2*>(ln.st_out + (long long)tn * ln.st_stride + 2ll * (m0 + threadIdx.x)) = make_float2(s, q);
-    }
-  }
   GTS(3);
 }
 
@@ -1171,13 +1039,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
   k64_tile<TA, TB, BM, false>(p, tm, tn, split, kt_begin, kt_end, DwFold{});
 }
-template <int BM, int LNM>   // the two sides of the LayerNorm fold (x W^T products only): LNM 1 = consumer (csmae_gemm_lnfold), 2 = producer (csmae_gemm_resid_stats)
-__global__ __launch_bounds__(512, 1) void gemm_bf16_k64_ln_kernel(GemmArgs p, LnArgs ln) {
-  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  k64_tile<false, false, BM, false, LNM>(p, tm, tn, 0, 0, p.ktiles, DwFold{}, ln);
-}
-
 // ---- grouped weight gradients: the dW products of a transformer block (qkv, proj, fc1, fc2 — same token axis K) in ONE launch.
 // A product on its own cannot fill the chip without cutting K into 10 .. 60 slices (768 x 768: 9 tiles), each of which pays a 256-KiB
 // fp32 slab store and a share of a separate reduce kernel; together the block's 108 (ViT-B encoder) / 48 (decoder) tiles need no or
@@ -1589,13 +1450,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 static int g_force_cfg = -1;  // tuning hook (tools/gemm_bench.py): -1 = heuristic
 extern "C" int csmae_gemm_force_tile(int cfg) { g_force_cfg = cfg; return 0; }
 
-// the LayerNorm-fold extras of a launch (see GemmArgs): producer side (st_out) and / or consumer side (st_in ...)
-struct GemmLn { float* st_out; const float* st_in; long long st_stride; int st_parts; const float* ln_c; float eps; float* mean; float* rstd; };
 static int gemm_core(int dtype, int transA, int transB, long long M, long long N, long long K,
                      const void* A, long long lda, const void* B, long long ldb,
                      void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
                      void* aux, long long ldaux, const void* resid, long long ldr,
-                     int splitk, void* stream, const GemmLn* ln) {
+                     int splitk, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0, "csmae_gemm: empty problem M=%lld N=%lld K=%lld", M, N, K);
   CSMAE_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "csmae_gemm: N and ldc must be multiples of 4 (N=%lld ldc=%lld)", N, ldc);
   const int q8 = (epilogue == 6 || epilogue == 7);   // CSMAE_EPI_GELU_Q8 / CSMAE_EPI_DGELU_Q8: gelu' as one byte per element
@@ -1611,32 +1470,6 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
   p.split_stride = M * ldc;
   p.colsum = (epilogue == EPI_SPLIT && transA && transB && dtype == CSMAE_BF16) ? reinterpret_cast<float*>(aux) : nullptr;
   p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = q8; p.q_out = nullptr;
-  LnArgs la{nullptr, nullptr, 0, 0, nullptr, 0.f, nullptr, nullptr};
-  if (ln) {   // LayerNorm fold: both sides live in the pipelined kernel's 16-byte-row bf16 epilogues
-    CSMAE_REQUIRE(dtype == CSMAE_BF16 && c_dtype == CSMAE_BF16 && !transA && !transB && splitk == 1 && g_force_cfg < 0 && ldc % 8 == 0 && N % 8 == 0,
-                  "csmae_gemm (LayerNorm fold): bf16 x W^T products with 8-element aligned rows only");
-    CSMAE_REQUIRE((ln->st_out != nullptr) != (ln->st_in != nullptr), "csmae_gemm (LayerNorm fold): a launch is either the producer or the consumer side");
-    if (ln->st_out) {
-      CSMAE_REQUIRE(epilogue == EPI_RESID && ldr % 8 == 0 && ((uintptr_t)resid & 15) == 0 && ln->st_stride >= 2 * M && ((uintptr_t)ln->st_out & 7) == 0,
-                    "csmae_gemm_resid_stats: residual epilogue with 16-byte aligned rows, st_stride >= 2 M");
-      la.st_out = ln->st_out; la.st_stride = ln->st_stride;
-    }
-    if (ln->st_in) {
-      CSMAE_REQUIRE((epilogue == EPI_NONE || (epilogue == EPI_GELU && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0)) && ln->st_parts >= 1 && ln->st_parts <= LN_MAXP && ln->ln_c && ln->mean && ln->rstd &&
-                    ln->st_stride >= 2 * M && ((uintptr_t)ln->st_in & 7) == 0 && ((uintptr_t)ln->ln_c & 15) == 0,
-                    "csmae_gemm_lnfold: plain or GELU epilogue, the partial statistics (at most 5 parts), c, mean and rstd are required");
-      la.st_in = ln->st_in; la.st_stride = ln->st_stride; la.st_parts = ln->st_parts; la.ln_c = ln->ln_c; la.ln_eps = ln->eps; la.ln_mean = ln->mean; la.ln_rstd = ln->rstd;
-    }
-  }
-  p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
-  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;
-  // buffer-addressed epilogue (epilogue_rows_bf16x8b): bit 8 of a_fmt (the field is the fp8 kernels' otherwise).  A lane's 8 columns are valid as a
-  // whole, and a byte offset up to 256 rows past the end of any tensor the epilogue touches must not wrap (rows beyond M are range-checked away)
-  if (dtype == CSMAE_BF16 && c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll &&
-      (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) && ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) &&
-      !getenv("CSMAE_EPI_POINTERS"))   // (A/B aid: the pointer-addressed epilogues)
-    p.a_fmt |= 256;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMAE_BF16) {
     CSMAE_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "csmae_gemm(bf16): lda and ldb must be multiples of 8 (lda=%lld ldb=%lld)", lda, ldb);
@@ -1655,7 +1488,6 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
     // fewer tiles than CUs (N = 768 outputs: 150 tiles) because it halves the bytes staged per flop; 256x128 never won.
     // 0: 128x128x32 (4 waves, 2 blocks/CU)   2: 256x256x32 (8 waves, 1 block/CU)   4: 256x256x64 software-pipelined (K-contiguous A)
     int cfg = (M >= 256 && N >= 256) ? ((!transA || transB) ? 4 : 2) : 0;
-    if (ln) cfg = 4;   // both sides of the LayerNorm fold live in the pipelined kernel's epilogues, whatever the size (edge tiles are zero-filled)
     if (cfg == 4 && !transA && splitk == 1) {  // 5: the same kernel with 192-row tiles, when it fills the CUs at least 10 % better
       const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256), t192 = (long long)cdiv(M, 192) * cdiv(N, 256);
       const long long c256 = cdiv(t256, 256) * 256, c192 = cdiv(t192, 256) * 192;
@@ -1669,7 +1501,6 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
     // the pipelined kernel fetches without per-piece predicates (k64_tile): K-contiguous operands need whole 64-wide K steps, and a byte offset up
     // to one tile past the end of an operand must not wrap
     if (cfg >= 4 && ((!(transA && transB) && K % 64 != 0) || ((transA ? K + 64 : M + 256) * lda * 2 >= 0xFFFFFFF0ll) || ((transB ? K + 64 : N + 256) * ldb * 2 >= 0xFFFFFFF0ll))) {
-      CSMAE_REQUIRE(!ln, "csmae_gemm (LayerNorm fold): K must be a multiple of 64");
       cfg = 2;
     }
     if (cfg >= 4) p.ktiles = cdiv(K, 64);
@@ -1684,14 +1515,7 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
     else if (cfg == 2) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, false>), grid, dim3(512), 0, st, p);  \
     else if (cfg == 3) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 256, 256, 128, 64, 4, true>), grid, dim3(512), 0, st, p);   \
     else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, 128, 128, 64, 64, 4, false>), grid, dim3(256), 0, st, p);
-    if (ln) {
-      CSMAE_REQUIRE(cfg == 4 || cfg == 5, "csmae_gemm (LayerNorm fold): needs the pipelined kernel");
-      if (la.st_in && cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<192, 1>), grid, dim3(512), 0, st, p, la);
-      else if (la.st_in) hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<256, 1>), grid, dim3(512), 0, st, p, la);
-      else if (cfg == 5) hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<192, 2>), grid, dim3(512), 0, st, p, la);
-      else hipLaunchKernelGGL((gemm_bf16_k64_ln_kernel<256, 2>), grid, dim3(512), 0, st, p, la);
-    }
-    else if (cfg == 5 && !transB) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, false, 192>), grid, dim3(512), 0, st, p);
+    if (cfg == 5 && !transB) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, false, 192>), grid, dim3(512), 0, st, p);
     else if (cfg == 5) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, true, 192>), grid, dim3(512), 0, st, p);
     else if (cfg == 4 && transA) CSMAE_LAUNCH((gemm_bf16_k64_kernel<true, true>), grid, dim3(512), 0, st, p);
     else if (cfg == 4 && !transB) CSMAE_LAUNCH((gemm_bf16_k64_kernel<false, false>), grid, dim3(512), 0, st, p);
@@ -1722,29 +1546,7 @@ extern "C" int csmae_gemm(int dtype, int transA, int transB, long long M, long l
                           void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
                           void* aux, long long ldaux, const void* resid, long long ldr,
                           int splitk, void* stream) {
-  return gemm_core(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, epilogue, aux, ldaux, resid, ldr, splitk, stream, nullptr);
-}
-
-// ---- LayerNorm folded into the GEMMs around it (timm Block, pre-norm: x -> norm -> Linear; MAE_ViT_Baseline.py:160-188).
-//   y = LN(x) W^T + b = rstd (x (W diag(gamma))^T - mean c) + (b + W beta),   c[n] = sum_k (W diag(gamma))[n,k]
-// so the residual stream x itself is the A operand and LayerNorm costs neither a kernel nor a round trip of its output through HBM:
-//  * csmae_gemm_resid_stats: the residual product that WRITES x (attn.proj / mlp.fc2, C = A B^T + bias + resid, bf16) also leaves, per row
-//    and 256-column tile tn, (sum, sum of squares) of the row segment it wrote at st_part[tn * part_stride + 2 m] (parts = ceil(N / 256));
-//  * csmae_gemm_lnfold: the product that CONSUMES LN(x) (attn.qkv: plain epilogue; mlp.fc1: GELU epilogue, aux as in csmae_gemm) folds the
-//    partials into mean / rstd per row (also written out for the backward pass), reads x as A and Wg = bf16(W diag(gamma)) as B;
-//  * csmae_ln_fold_weights (norm.hip) makes Wg, c and b' = b + W beta from the fp32 masters.
-extern "C" int csmae_gemm_resid_stats(long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
-                                      const float* bias, const void* resid, long long ldr, float* st_part, long long part_stride, void* stream) {
-  CSMAE_REQUIRE(st_part, "csmae_gemm_resid_stats: null statistics buffer");
-  const GemmLn ln{st_part, nullptr, part_stride, 0, nullptr, 0.f, nullptr, nullptr};
-  return gemm_core(CSMAE_BF16, 0, 0, M, N, K, A, lda, B, ldb, C, ldc, CSMAE_BF16, bias, EPI_RESID, nullptr, 0, resid, ldr, 1, stream, &ln);
-}
-extern "C" int csmae_gemm_lnfold(long long M, long long N, long long K, const void* x, long long ldx, const void* Wg, long long ldw, void* C, long long ldc,
-                                 const float* c, const float* bias_folded, const float* st_part, long long part_stride, int parts, float eps,
-                                 float* mean, float* rstd, int epilogue, void* aux, long long ldaux, void* stream) {
-  CSMAE_REQUIRE(st_part, "csmae_gemm_lnfold: null statistics buffer");
-  const GemmLn ln{nullptr, st_part, part_stride, parts, c, eps, mean, rstd};
-  return gemm_core(CSMAE_BF16, 0, 0, M, N, K, x, ldx, Wg, ldw, C, ldc, CSMAE_BF16, bias_folded, epilogue, aux, ldaux, nullptr, 0, 1, stream, &ln);
+  return gemm_core(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, epilogue, aux, ldaux, resid, ldr, splitk, stream);
 }
 
 // ------------------------------------------------------------------------------------ weight gradients

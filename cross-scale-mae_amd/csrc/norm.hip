@@ -254,38 +254,6 @@ extern "C" int csmae_ln_param_reduce(int count, long long M, int D, const float*
   return csmae_check_launch("csmae_ln_param_reduce");
 }
 
-// ------------------------------------------------------------------------------------------ LayerNorm fold: weight side
-// For every (LayerNorm, Linear) pair that is folded (csmae_gemm_lnfold in gemm.hip): Wg = bf16(W diag(gamma)), c[n] = sum_k Wg[n,k] (of the
-// ROUNDED values: the GEMM subtracts mean * c from a product over exactly these bf16 numbers), b'[n] = b[n] + sum_k W[n,k] beta[k] (fp32).
-// One wave per output row; one launch for all pairs of the model: desc[k] = {W, b, gamma, beta offsets in `p` (floats), N, K, Wg offset in
-// `wg` (bf16 elements), c offset in `vec` (b' follows at + N)}.  Runs once per optimizer step (the masters changed), 6 B per weight element.
-__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const long long* __restrict__ desc, const float* __restrict__ p, bf16_t* __restrict__ wg, float* __restrict__ vec) {
-  const long long* d = desc + (long long)blockIdx.y * 8;
-  const int N = (int)d[4], K = (int)d[5];
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= N) return;
-  const float* W = p + d[0] + (long long)row * K;
-  const float* gamma = p + d[2];
-  const float* beta = p + d[3];
-  bf16_t* o = wg + d[6] + (long long)row * K;
-  float cs = 0.f, wb = 0.f;
-  for (int k = lane * 4; k < K; k += 256) {
-    const f4_t w = *reinterpret_cast<const f4_t*>(W + k), gm = *reinterpret_cast<const f4_t*>(gamma + k), bt = *reinterpret_cast<const f4_t*>(beta + k);
-    const f4_t v = w * gm;
-    uint2 u; u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
-    *reinterpret_cast<uint2*>(o + k) = u;
-    cs += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) + (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u));
-    wb += (w[0] * bt[0] + w[1] * bt[1]) + (w[2] * bt[2] + w[3] * bt[3]);
-  }
-  cs = wave_sum(cs); wb = wave_sum(wb);
-  if (lane == 0) { vec[d[7] + row] = cs; vec[d[7] + N + row] = p[d[1] + row] + wb; }
-}
-extern "C" int csmae_ln_fold_weights(int count, int max_rows, const long long* desc, const float* p, void* wg, float* vec, void* stream) {
-  CSMAE_REQUIRE(count > 0 && max_rows > 0 && desc && p && wg && vec, "csmae_ln_fold_weights: bad arguments");
-  hipLaunchKernelGGL(ln_fold_weights_kernel, dim3(cdiv(max_rows, 4), count), dim3(256), 0, (hipStream_t)stream, desc, p, (bf16_t*)wg, vec);
-  return csmae_check_launch("csmae_ln_fold_weights");
-}
-
 // ------------------------------------------------------------------------------------------ BatchNorm(token axis)+ReLU
 // u is [N*L, Hp]; channel = token position l; statistics over the N*Hp values {u[n*L + l, :]} (models_mae/MLP.py:7).
 template <typename T>

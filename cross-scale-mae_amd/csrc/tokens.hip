@@ -177,22 +177,9 @@ extern "C" int csmae_patch_gather(int dtype, long long rows, int keep, int N, in
 }
 
 // ------------------------------------------------------------------------------------------ pos-embed add + cls prepend
-// (sum, sum of squares) of the row a workgroup has just written, for the LayerNorm fold (csmae_gemm_lnfold: the first block of a stack has
-// no residual GEMM in front of it whose epilogue could supply them)
-__device__ __forceinline__ void row_stats_store(float s, float q, float* stats, long long row) {
-  __shared__ float red[8];
-  s = wave_sum(s); q = wave_sum(q);
-  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[2 * w] = s; red[2 * w + 1] = q; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < nw; ++k) { s += red[2 * k]; q += red[2 * k + 1]; }
-    *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(s, q);
-  }
-}
 template <typename TX>   // TX: type of the residual stream (fp32; bf16 in throughput mode)
 __global__ __launch_bounds__(256) void embed_assemble_kernel(int keep, int D, const float* __restrict__ tok, const float* __restrict__ pos,
-                                                             const float* __restrict__ cls, const int* __restrict__ ids_keep, TX* __restrict__ x, float* __restrict__ stats) {
+                                                             const float* __restrict__ cls, const int* __restrict__ ids_keep, TX* __restrict__ x) {
   const long long n2 = blockIdx.x;
   const int t = blockIdx.y;  // 0 = cls
   const int dv = D >> 2;
@@ -204,22 +191,15 @@ __global__ __launch_bounds__(256) void embed_assemble_kernel(int keep, int D, co
     a = tok + r * D;
     pp = pos + (long long)(1 + ids_keep[r]) * D;
   }
-  float s = 0.f, q = 0.f;
-  for (int c = threadIdx.x; c < dv; c += blockDim.x) {
-    f4_t v = *reinterpret_cast<const f4_t*>(a + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4);
-    st4<TX>(dst + c * 4, v);
-    v = round4<TX>(v);   // (statistics of the values as stored)
-    s += (v[0] + v[1]) + (v[2] + v[3]);
-    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-  }
-  if (stats) row_stats_store(s, q, stats, n2 * (keep + 1) + t);
+  for (int c = threadIdx.x; c < dv; c += blockDim.x)
+    st4<TX>(dst + c * 4, *reinterpret_cast<const f4_t*>(a + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4));
 }
 extern "C" int csmae_embed_assemble(int x_dtype, long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep, void* x,
-                                    float* stats, void* stream) {
+                                    void* stream) {
   CSMAE_REQUIRE(B2 > 0 && keep >= 0 && D % 4 == 0, "csmae_embed_assemble: bad geometry");
   const dim3 grid((unsigned)B2, keep + 1), block(D >= 1024 ? 256 : 128);
-  if (x_dtype == CSMAE_F32) hipLaunchKernelGGL(embed_assemble_kernel<float>, grid, block, 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, (float*)x, stats);
-  else if (x_dtype == CSMAE_BF16) hipLaunchKernelGGL(embed_assemble_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, (bf16_t*)x, stats);
+  if (x_dtype == CSMAE_F32) hipLaunchKernelGGL(embed_assemble_kernel<float>, grid, block, 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, (float*)x);
+  else if (x_dtype == CSMAE_BF16) hipLaunchKernelGGL(embed_assemble_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, keep, D, tok, pos, cls, ids_keep, (bf16_t*)x);
   else { csmae_set_error("csmae_embed_assemble: bad dtype %d", x_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_embed_assemble");
 }
@@ -267,8 +247,7 @@ extern "C" int csmae_embed_assemble_bwd(int in_dtype, int dtype, long long B2, i
 // xd[n,0] = z[n,0] + dpos[0];  xd[n,1+j] = (r = ids_restore[n,j]) < keep ? z[n,1+r] : mask_token ;  + dpos[1+j]
 template <typename TX>
 __global__ __launch_bounds__(128) void unshuffle_fwd_kernel(int L, int keep, int Dd, const float* __restrict__ z, const float* __restrict__ mask_token,
-                                                            const float* __restrict__ dpos, const long long* __restrict__ ids_restore, TX* __restrict__ xd,
-                                                            float* __restrict__ stats) {
+                                                            const float* __restrict__ dpos, const long long* __restrict__ ids_restore, TX* __restrict__ xd) {
   const long long n = blockIdx.x;
   const int j = blockIdx.y;  // 0 = cls
   const int dv = Dd >> 2;
@@ -277,22 +256,15 @@ __global__ __launch_bounds__(128) void unshuffle_fwd_kernel(int L, int keep, int
   else { long long r = ids_restore[n * L + j - 1]; src = r < keep ? z + (n * (keep + 1) + 1 + r) * Dd : mask_token; }
   TX* dst = xd + (n * (L + 1) + j) * Dd;
   const float* pp = dpos + (long long)j * Dd;
-  float s = 0.f, q = 0.f;
-  for (int c = threadIdx.x; c < dv; c += blockDim.x) {
-    f4_t v = *reinterpret_cast<const f4_t*>(src + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4);
-    st4<TX>(dst + c * 4, v);
-    v = round4<TX>(v);   // (statistics of the values as stored)
-    s += (v[0] + v[1]) + (v[2] + v[3]);
-    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-  }
-  if (stats) row_stats_store(s, q, stats, n * (L + 1) + j);
+  for (int c = threadIdx.x; c < dv; c += blockDim.x)
+    st4<TX>(dst + c * 4, *reinterpret_cast<const f4_t*>(src + c * 4) + *reinterpret_cast<const f4_t*>(pp + c * 4));
 }
 extern "C" int csmae_unshuffle_fwd(int x_dtype, long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
-                                   const long long* ids_restore, void* xd, float* stats, void* stream) {
+                                   const long long* ids_restore, void* xd, void* stream) {
   CSMAE_REQUIRE(B2 > 0 && L > 0 && keep >= 0 && keep <= L && Dd % 4 == 0, "csmae_unshuffle_fwd: bad geometry");
   const dim3 grid((unsigned)B2, L + 1);
-  if (x_dtype == CSMAE_F32) hipLaunchKernelGGL(unshuffle_fwd_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, (float*)xd, stats);
-  else if (x_dtype == CSMAE_BF16) hipLaunchKernelGGL(unshuffle_fwd_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, (bf16_t*)xd, stats);
+  if (x_dtype == CSMAE_F32) hipLaunchKernelGGL(unshuffle_fwd_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, (float*)xd);
+  else if (x_dtype == CSMAE_BF16) hipLaunchKernelGGL(unshuffle_fwd_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, L, keep, Dd, z, mask_token, dpos, ids_restore, (bf16_t*)xd);
   else { csmae_set_error("csmae_unshuffle_fwd: bad dtype %d", x_dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_unshuffle_fwd");
 }

@@ -85,24 +85,6 @@ int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, const void*
                    const void* resid, long long ldr, const float* dq_a, const float* dq_b,
                    void* q_out /* nullable: also emit C as fp8 bytes [M][ldq] in q_fmt for the GEMM that reads it next (delayed scaling) */,
                    long long ldq, int q_fmt, const float* q_amax_prev /* [64] */, float* q_amax_next /* [64] */, float* q_dq, void* stream);
-/* ---- LayerNorm folded into the Linear layers around it (timm Block is pre-norm: x -> norm1 -> attn.qkv, x -> norm2 -> mlp.fc1;
- * MAE_ViT_Baseline.py:160-188,261-262,289-290; throughput mode, bf16 residual stream):
- *   LN(x) W^T + b = rstd (x (W diag(gamma))^T - mean c) + (b + W beta),  c[n] = sum_k (W diag(gamma))[n,k]
- * csmae_gemm_resid_stats = csmae_gemm(bf16, x W^T, RESID epilogue) — attn.proj / mlp.fc2, the products that WRITE the stream — which also
- *   leaves (sum, sum of squares) of every row segment it writes: st_part[tn * part_stride + 2 m + {0,1}], tn = column tile of 256
- *   (part_stride >= 2 M floats, ceil(N / 256) parts);
- * csmae_gemm_lnfold: C[M,N] = LN(x)[M,K] W^T + b with x (bf16, the stream itself) as A and Wg = bf16(W diag(gamma)) as B; folds `parts`
- *   partials into mean / rstd per row (eps as nn.LayerNorm; both are written out: the backward pass needs them); epilogue NONE
- *   (attn.qkv) or GELU / GELU_Q8 (mlp.fc1, aux = gelu');
- * csmae_ln_fold_weights: one launch for `count` (LayerNorm, Linear) pairs: desc (device, 8 int64 per pair) = {W, b, gamma, beta offsets
- *   in p (floats), N, K, Wg offset in wg (bf16 elements), c offset in vec (b + W beta follows at + N)}; max_rows = largest N.
- * Rows 8-element aligned (K, N, ld* multiples of 8); anything else is an error (no fallback: run csmae_layernorm_fwd + csmae_gemm instead). */
-int csmae_gemm_resid_stats(long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc,
-                           const float* bias, const void* resid, long long ldr, float* st_part, long long part_stride, void* stream);
-int csmae_gemm_lnfold(long long M, long long N, long long K, const void* x, long long ldx, const void* Wg, long long ldw, void* C, long long ldc,
-                      const float* c, const float* bias_folded, const float* st_part, long long part_stride, int parts, float eps,
-                      float* mean, float* rstd, int epilogue, void* aux, long long ldaux, void* stream);
-int csmae_ln_fold_weights(int count, int max_rows, const long long* desc, const float* p, void* wg, float* vec, void* stream);
 /* tuning hook for tools/gemm_bench.py: force the bf16 block tile (0: 128x128, 1: 256x128, 2: 256x256, -1: heuristic) */
 int csmae_gemm_force_tile(int cfg);
 
@@ -160,11 +142,11 @@ int csmae_patch_gather(int dtype, long long rows, int keep, int N, int C, int S,
                        const int* ids_keep, void* out, long long ld, void* stream);
 /* ---- MAE_ViT_Baseline.py:248,253-256: + encoder_pos_embed, cls prepend (and its backward) */
 int csmae_embed_assemble(int x_dtype, long long B2, int keep, int D, const float* tok, const float* pos, const float* cls, const int* ids_keep,
-                         void* x, float* stats /* nullable: (sum, sum of squares) per row written, [rows][2], for csmae_gemm_lnfold */, void* stream);
+                         void* x, void* stream);
 int csmae_embed_assemble_bwd(int in_dtype, int dtype, long long B2, int keep, int D, const void* dx, void* dtok, float* dcls, void* stream);
 /* ---- MAE_ViT_Baseline.forward_decoder (:273-283): mask-token fill, gather(ids_restore), + decoder_pos_embed */
 int csmae_unshuffle_fwd(int x_dtype, long long B2, int L, int keep, int Dd, const float* z, const float* mask_token, const float* dpos,
-                        const long long* ids_restore, void* xd, float* stats /* nullable: as csmae_embed_assemble */, void* stream);
+                        const long long* ids_restore, void* xd, void* stream);
 int csmae_unshuffle_bwd(int in_dtype, int dtype, long long B2, int L, int keep, int Dd, const void* dxd, const long long* ids_restore, void* dz,
                         float* dmask_token, void* stream);
 /* ---- `[:, 1:, :]` views around the predictor (MAE_ViT_MsLdCeCd.py:57-58) */

@@ -436,17 +436,6 @@ def test_fullsize_geometry_vs_reference_and_oracle(tag):
     _fullsize_case(tag, (torch.float32, torch.bfloat16))
 
 
-@pytest.mark.parametrize("tag", ["vitb16_224", "vith14_224"])
-def test_fullsize_geometry_with_layernorm_folded_into_the_gemms(tag, monkeypatch):
-    """The same fixtures through the optional LayerNorm fold (CSMAE_LNFOLD=1: norm1 -> attn.qkv and norm2 -> mlp.fc1 as csmae_gemm_lnfold,
-    the row statistics from the residual epilogues / the stack-boundary kernels; DESIGN §5 has why it is not the default), bf16 engine,
-    at the tolerances of the un-folded path."""
-    monkeypatch.setenv("CSMAE_LNFOLD", "1")
-    m = _fullsize_case(tag, (torch.bfloat16,))
-    eng = m._engines[torch.bfloat16]
-    assert eng.fold and "sp" in eng.ws.enc
-
-
 def _fullsize_case(tag, dtypes):
     """MAE_ViT_MsLdCeCd at the geometries BASELINE.json's configs[1..4] are quoted on — ViT-B/16 224^2 (L = 196, Te = 50, Td = 197),
     ViT-L/16 224^2, ViT-L/16 256^2 4-band, ViT-H/14 224^2 (hd = 80, P = 588) — against (a) the REFERENCE's outputs on the same seeded

@@ -575,157 +575,6 @@ def test_gemm_gelu_epilogues_with_8bit_derivative(ops):
         assert int(g1.max()) > 200 and int(g1.min()) < 30      # (codes actually written)
 
 
-LNFOLD_SHAPES = [(400, 768, 768), (1000, 512, 512), (130, 128, 128), (68, 64, 64), (300, 1280, 1280), (512, 1024, 1024)]   # (rows, D = K of the consumer = N of the producer, K of the producer)
-
-
-@pytest.mark.parametrize("MDK", LNFOLD_SHAPES)
-def test_gemm_resid_stats_is_the_residual_gemm_plus_row_statistics(ops, MDK):
-    """csmae_gemm_resid_stats (attn.proj / mlp.fc2 in throughput mode): the output is bit-identical to csmae_gemm with the RESID epilogue,
-    and st_part[tn, m] = (sum, sum of squares) of row m over column tile tn — against fp32 torch on the same operands.  Ragged M, one to five
-    column tiles, K from one to 20 K steps; a row-range view of a larger statistics buffer (what the two forward streams pass)."""
-    from csmae_hip import EPI_RESID
-    M, D, K = MDK
-    a = dev(rnd(M, K, seed=40).to(torch.bfloat16))
-    w = dev((rnd(D, K, seed=41) * K ** -0.5).to(torch.bfloat16))
-    bias = dev(rnd(D, seed=42) * 0.3)
-    resid = dev((rnd(M, D, seed=43) * 2.0 + 0.7).to(torch.bfloat16))
-    parts = (D + 255) // 256
-    o1, o2 = (torch.empty(M, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
-    big = torch.full((parts, M + 24, 2), float("nan"), device="cuda")
-    st = big[:, 16:16 + M]
-    ops.gemm(a, w, o1, bias=bias, epilogue=EPI_RESID, resid=resid)
-    ops.gemm_resid_stats(a, w, o2, bias, resid, st)
-    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16)), "statistics variant changed the residual product"
-    assert bool(torch.isnan(big[:, :16]).all()) and bool(torch.isnan(big[:, 16 + M:]).all()), "wrote outside its row range"
-    ref = a.float().cpu() @ w.float().cpu().t() + bias.cpu() + resid.float().cpu()
-    assert_close(o2, ref, 1e-2, 2e-2, "residual product")
-    got = o2.float().cpu()                                   # the statistics are those of the values as STORED (bf16)
-    for tn in range(parts):
-        seg = got[:, tn * 256:(tn + 1) * 256]
-        assert_close(st[tn, :, 0], seg.sum(1), 1e-5, 1e-3, f"row sums tile {tn}")
-        assert_close(st[tn, :, 1], (seg * seg).sum(1), 1e-5, 1e-3, f"row sums of squares tile {tn}")
-
-
-def test_ln_fold_weights(ops):
-    """Wg = bf16(W diag(gamma)), c = rowsum of the ROUNDED Wg, b' = b + W beta; several (LayerNorm, Linear) pairs in one launch."""
-    g = torch.Generator().manual_seed(5)
-    pairs = [(96, 64), (2304, 768), (40, 128)]
-    flat, desc, ow, ov = [], [], 0, 0
-    off = 0
-    host = []
-    for N, K in pairs:
-        W, b, gm, bt = torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g), torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.2
-        offs = []
-        for t in (W.reshape(-1), b, gm, bt):
-            offs.append(off)
-            flat.append(t)
-            pad = (-t.numel()) % 8
-            flat.append(torch.zeros(pad))
-            off += t.numel() + pad
-        desc.append(offs + [N, K, ow, ov])
-        host.append((W, b, gm, bt, ow, ov))
-        ow += (N * K + 7) // 8 * 8
-        ov += (2 * N + 7) // 8 * 8
-    p = dev(torch.cat(flat))
-    wg = torch.zeros(ow, device="cuda", dtype=torch.bfloat16)
-    vec = torch.zeros(ov, device="cuda")
-    ops.ln_fold_weights(len(pairs), max(n for n, _ in pairs), dev(torch.tensor(desc, dtype=torch.long)), p, wg, vec)
-    for (N, K), (W, b, gm, bt, o_w, o_v) in zip(pairs, host):
-        want = (W * gm).to(torch.bfloat16)
-        got = wg[o_w:o_w + N * K].view(N, K).cpu()
-        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), "Wg"
-        assert_close(vec[o_v:o_v + N], want.float().sum(1), 1e-5, 1e-4, "c")
-        assert_close(vec[o_v + N:o_v + 2 * N], b + W @ bt, 1e-5, 1e-4, "b'")
-
-
-@pytest.mark.parametrize("MDK", LNFOLD_SHAPES)
-@pytest.mark.parametrize("gelu", [False, True])
-def test_gemm_lnfold_vs_fp32_layer_norm_plus_linear(ops, MDK, gelu):
-    """The folded product (attn.qkv: plain epilogue; mlp.fc1: GELU + 8-bit gelu') against torch fp32 `layer_norm(x) @ W.T + b` on the same
-    bf16 stream x; the row statistics it leaves for the backward pass against torch's; and the whole chain producer -> consumer against
-    the un-folded kernels (csmae_layernorm_fwd + csmae_gemm).  The stream has a per-row offset several times its spread, which is what
-    the mean * c subtraction has to survive."""
-    from csmae_hip import EPI_GELU, EPI_RESID
-    M, D, Kp = MDK
-    N = 3 * D if not gelu else 4 * D
-    # the stream comes out of a residual product (as in the step), so that the partial statistics are the producer's own
-    a = dev(rnd(M, Kp, seed=50).to(torch.bfloat16))
-    wp = dev((rnd(D, Kp, seed=51) * Kp ** -0.5).to(torch.bfloat16))
-    bp = dev(rnd(D, seed=52) * 0.3)
-    resid = dev((rnd(M, D, seed=53) * 1.5 + rnd(M, 1, seed=54) * 4.0).to(torch.bfloat16))
-    parts = (D + 255) // 256
-    x = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
-    st = torch.empty(parts, M, 2, device="cuda")
-    ops.gemm_resid_stats(a, wp, x, bp, resid, st)
-    W, b = rnd(N, D, seed=55) * D ** -0.5, rnd(N, seed=56) * 0.2
-    gm, bt = torch.rand(D, generator=torch.Generator().manual_seed(57)) + 0.5, rnd(D, seed=58) * 0.3
-    flat = torch.cat([W.reshape(-1), b, gm, bt])
-    desc = torch.tensor([[0, N * D, N * D + N, N * D + N + D, N, D, 0, 0]], dtype=torch.long)
-    wg = torch.empty(N * D, device="cuda", dtype=torch.bfloat16)
-    vec = torch.empty(2 * N, device="cuda")
-    ops.ln_fold_weights(1, N, dev(desc), dev(flat), wg, vec)
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
-    aux = torch.empty(M, N, device="cuda", dtype=torch.uint8) if gelu else None
-    ops.gemm_lnfold(x, wg.view(N, D), out, vec[:N], vec[N:], st, parts, mean, rstd, epilogue=EPI_GELU if gelu else 0, aux=aux)
-    xf = x.float().cpu()
-    pre = torch.nn.functional.layer_norm(xf, (D,), gm, bt, eps=1e-6) @ W.t() + b
-    ref = torch.nn.functional.gelu(pre) if gelu else pre
-    assert_close(out, ref, 1.5e-2, 2.5e-2, f"folded LayerNorm + Linear {M}x{N}x{D}")
-    assert_close(mean, xf.mean(1), 1e-4, 1e-4, "mean")
-    assert_close(rstd, (xf.var(1, unbiased=False) + 1e-6).rsqrt(), 2e-4, 1e-5, "rstd")
-    if gelu:
-        p8 = pre[:8].clone().requires_grad_(True)
-        torch.nn.functional.gelu(p8).sum().backward()
-        gp = p8.grad
-        assert float(((aux[:8].float().cpu() - 26.0) / 200.0 - gp).abs().max()) < 2.5e-3 + 2.5e-2   # (bf16-level differences in the pre-activation move gelu' by up to ~1 %)
-    # against the un-folded kernels on the same stream: both are bf16 paths, they must agree to bf16 rounding of the output
-    y = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
-    m2, r2 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
-    ops.layernorm_fwd(x, dev(gm), dev(bt), y, m2, r2)
-    out2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    aux2 = torch.empty(M, N, device="cuda", dtype=torch.uint8) if gelu else None
-    ops.gemm(y, dev(W.to(torch.bfloat16)), out2, bias=dev(b), epilogue=EPI_GELU if gelu else 0, aux=aux2)
-    assert_close(out, out2, 1.5e-2, 2.5e-2, "folded vs un-folded kernels")
-    assert_close(mean, m2, 1e-4, 1e-4, "mean vs ln_fwd")
-    assert_close(rstd, r2, 2e-4, 1e-5, "rstd vs ln_fwd")
-    # the folded product is at least as close to fp32 as the un-folded one (it rounds the normalised activations not at all)
-    e_fold, e_plain = float((out.float().cpu() - ref).abs().mean()), float((out2.float().cpu() - ref).abs().mean())
-    assert e_fold <= 1.25 * e_plain + 1e-4, (e_fold, e_plain)
-
-
-def test_stack_boundary_kernels_emit_row_statistics(ops):
-    """embed_assemble / unshuffle_fwd with a statistics buffer: (sum, sum of squares) of every row they write (the first block of a stack
-    folds its norm1 from these), same rows as without."""
-    B2, keep, D, L = 4, 5, 64, 16
-    tok, pos, cls = rnd(B2 * keep, D, seed=60), rnd(L + 1, D, seed=61), rnd(D, seed=62)
-    ids = torch.stack([torch.randperm(L, generator=torch.Generator().manual_seed(70 + i))[:keep] for i in range(B2)]).int()
-    x0, x1 = (torch.empty(B2 * (keep + 1), D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
-    st = torch.empty(B2 * (keep + 1), 2, device="cuda")
-    ops.embed_assemble(dev(tok), dev(pos), dev(cls), dev(ids), x0, B2, keep)
-    ops.embed_assemble(dev(tok), dev(pos), dev(cls), dev(ids), x1, B2, keep, stats=st)
-    assert torch.equal(x0.view(torch.int16), x1.view(torch.int16))
-    rows = x1.float().cpu()                                   # statistics of the values as stored (bf16)
-    assert_close(rows, torch.cat([torch.cat([(cls + pos[0])[None], tok[n * keep:(n + 1) * keep] + pos[1 + ids[n].long()]]) for n in range(B2)]), 1e-2, 1e-2, "embed rows")
-    assert_close(st[:, 0], rows.sum(1), 1e-5, 1e-4, "embed row sums")
-    assert_close(st[:, 1], (rows * rows).sum(1), 1e-5, 1e-4, "embed row sums of squares")
-    Dd = 256
-    z, mt, dpos = rnd(B2 * (keep + 1), Dd, seed=63), rnd(Dd, seed=64), rnd(L + 1, Dd, seed=65)
-    ids_restore = torch.stack([torch.randperm(L, generator=torch.Generator().manual_seed(80 + i)) for i in range(B2)])
-    xd0, xd1 = (torch.empty(B2 * (L + 1), Dd, device="cuda", dtype=torch.bfloat16) for _ in range(2))
-    sd = torch.empty(B2 * (L + 1), 2, device="cuda")
-    ops.unshuffle_fwd(dev(z), dev(mt), dev(dpos), dev(ids_restore), xd0, B2, L, keep)
-    ops.unshuffle_fwd(dev(z), dev(mt), dev(dpos), dev(ids_restore), xd1, B2, L, keep, stats=sd)
-    assert torch.equal(xd0.view(torch.int16), xd1.view(torch.int16))
-    zz = z.view(B2, keep + 1, Dd)
-    full = torch.cat([zz[:, 1:], mt.expand(B2, L - keep, Dd)], 1)
-    want = torch.cat([zz[:, :1], torch.gather(full, 1, ids_restore[:, :, None].expand(B2, L, Dd))], 1) + dpos
-    assert_close(xd1, want.reshape(-1, Dd), 1e-2, 1e-2, "unshuffle rows")
-    want = xd1.float().cpu()
-    assert_close(sd[:, 0], want.sum(1), 1e-5, 1e-3, "unshuffle row sums")
-    assert_close(sd[:, 1], (want * want).sum(1), 1e-5, 1e-3, "unshuffle row sums of squares")
-
-
 def test_stack_boundaries_bf16_stream(ops):
     """embed_assemble / unshuffle_fwd write, embed_assemble_bwd / unshuffle_bwd read the bf16 residual stream; bf16 -> fp32 cast."""
     B2, keep, D, L = 4, 5, 64, 16
