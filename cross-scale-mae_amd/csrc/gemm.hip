@@ -1470,6 +1470,15 @@ static int gemm_core(int dtype, int transA, int transB, long long M, long long N
   p.split_stride = M * ldc;
   p.colsum = (epilogue == EPI_SPLIT && transA && transB && dtype == CSMAE_BF16) ? reinterpret_cast<float*>(aux) : nullptr;
   p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = q8; p.q_out = nullptr;
+  p.A = A; p.B = B; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = splitk;
+  // buffer-addressed epilogue (epilogue_rows_bf16x8b): bit 8 of a_fmt (the field is the fp8 kernels' otherwise).  A lane's 8 columns are valid as a
+  // whole, and a byte offset up to 256 rows past the end of any tensor the epilogue touches must not wrap (rows beyond M are range-checked away)
+  if (dtype == CSMAE_BF16 && c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll &&
+      (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) && ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) &&
+      !getenv("CSMAE_EPI_POINTERS"))   // (A/B aid: the pointer-addressed epilogues)
+    p.a_fmt |= 256;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMAE_BF16) {
     CSMAE_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "csmae_gemm(bf16): lda and ldb must be multiples of 8 (lda=%lld ldb=%lld)", lda, ldb);
