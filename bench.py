@@ -109,7 +109,7 @@ SETTLE_STEPS = 10
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)   # BASELINE.md §6 protocol: >= 50 timed steps (the driver passes its own --steps)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (the headline metric is defined at 128)")
     ap.add_argument("--preset", type=str, default="base", choices=list(PRESETS), help="single-GPU slice of another BASELINE.json config (not the headline)")

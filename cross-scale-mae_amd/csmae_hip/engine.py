@@ -727,8 +727,13 @@ class Engine:
                 self.aux.wait_stream(main)   # (workspace reuse: the previous step's backward read E / zc on the main stream) — BEFORE the trunks are
                                              # enqueued: the contrastive branch then starts when both encoders are done, under the decoders' GEMMs
             evs = []
-            gens = [trunk(0, cuts[1], st, main, evs)] + [trunk(cuts[k], cuts[k + 1] - cuts[k], self._fwd_streams[k - 1].cuda_stream, self._fwd_streams[k - 1], evs)
-                                                          for k in range(1, nch)]
+            # which chunk the main stream takes: with the per-view heads the CROP's (the last chunk) — the main stream starts first and tends to
+            # finish first, and the predictor that follows the crop's decoder is the longest tail of the forward pass (CSMAE_FWD_SWAP=0: the original's)
+            order = list(range(nch))
+            if view_heads and self.has_pred and os.environ.get("CSMAE_FWD_SWAP", "1") != "0":
+                order = [nch - 1] + list(range(nch - 1))
+            lanes = [(st, main)] + [(so.cuda_stream, so) for so in self._fwd_streams[: nch - 1]]
+            gens = [trunk(cuts[k], cuts[k + 1] - cuts[k], lanes[i][0], lanes[i][1], evs) for i, k in enumerate(order)]
             if os.environ.get("CSMAE_FWD_SEQ_ENQUEUE"):  # tuning aid: one trunk after the other, as before
                 for g in gens:
                     for _ in g:
@@ -922,6 +927,8 @@ class Engine:
                 zeroed.record(self.side)
         ops.gate_accumulate(ws.losses, self.flat.gate, accumulate, st=st)   # (the gate slot sits behind `total`: written here, not cleared)
         ws.gout.copy_(gout.reshape(1).to(torch.float32))
+        head_start = self._event()
+        head_start.record(self.main)
         kind, npx = c["loss"], c["norm_pix"]
         # reconstruction head
         extra = None
@@ -938,14 +945,39 @@ class Engine:
         if self.has_pred:
             kcd = c["loss_cd"]
             bn = "predictor.1."
-            ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
-                              da_lp=ws.dv, dt_acc=ws.demb, st=st)
-            self._dw(ws.dv, ws.r, "predictor.3")
-            ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=st)
-            ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=st)
-            self._dw(ws.dr, ws.pin, "predictor.0")
-            ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=st)
-            ops.rows_scatter_add(ws.dpin, ws.demb, L, Td, N * Td + 1, st=st)
+            timed = ops._timer is not None or bool(os.environ.get("CSMAE_DW_MAIN"))
+            if timed or os.environ.get("CSMAE_HEADS_BWD_SERIAL"):   # (one chain on the main stream: per-kernel timing, A/B aid)
+                ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
+                                  da_lp=ws.dv, dt_acc=ws.demb, st=st)
+                self._dw(ws.dv, ws.r, "predictor.3")
+                ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=st)
+                ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=st)
+                self._dw(ws.dr, ws.pin, "predictor.0")
+                ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=st)
+                ops.rows_scatter_add(ws.dpin, ws.demb, L, Td, N * Td + 1, st=st)
+            else:
+                # The predictor's backward (pair loss -> Linear -> BatchNorm/ReLU -> Linear: four kernels, ~340 us) depends on the reconstruction
+                # head's (recon_bwd -> decoder_pred dX, above) only through the buffer both add into.  It runs on the auxiliary stream beside
+                # it; the two contributions to the decoder-embedding gradient — minus the loss gradient into the original's rows (the target is
+                # not detached), the predictor's input gradient into the crop's — are added by ONE kernel once both chains are done.  The
+                # weight-gradient launches wait for events recorded on the auxiliary stream.
+                aux, ast = self.aux, self.aux.cuda_stream
+                aux.wait_event(head_start)                   # gout, and everything the forward pass left on the main stream
+                if zeroed is not None:
+                    aux.wait_event(zeroed)                   # (BatchNorm's parameter gradients go straight into the flat buffer)
+                ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
+                                  da_lp=ws.dv, st=ast)
+                e1 = self._event()
+                e1.record(aux)
+                self._dw_group([(ws.dv, ws.r, "predictor.3")], ready=e1)
+                ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=ast)
+                ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=ast)
+                e2 = self._event()
+                e2.record(aux)
+                self._dw_group([(ws.dr, ws.pin, "predictor.0")], ready=e2)
+                ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=ast)
+                self.main.wait_stream(aux)
+                ops.rows_scatter_add2(ws.dv, -1.0, 1, ws.dpin, 1.0, N * Td + 1, ws.demb, L, Td, st=st)
         # decoder
         lp_stream = self.res_dtype != torch.float32   # bf16 residual-gradient stream: the ping-pong buffers are the stream itself
         pd, Nd2 = ws.ln_part_d, 2 * c["Nd"]

@@ -327,6 +327,13 @@ def rows_gather_idx(x, ids, keep, out, st=None):
     return out
 
 
+def rows_scatter_add2(a, scale_a, off_a, b, scale_b, off_b, dst, group, gstride, st=None):
+    """dst[view(r) + off_a] += scale_a * a[r]; dst[view(r) + off_b] += scale_b * b[r]   (view(r) = (r // group) * gstride + r % group)."""
+    assert a.shape == b.shape and a.dtype == b.dtype and dst.dtype == torch.float32
+    check(load().csmae_rows_scatter_add2(dt(a), a.shape[0], a.shape[1], _p(a), scale_a, off_a, _p(b), scale_b, off_b, group, gstride, _p(dst),
+                                         st if st is not None else stream()), "csmae_rows_scatter_add2")
+
+
 def rows_scatter_add(src, dst, group, gstride, off, scale=1.0, st=None):
     check(load().csmae_rows_scatter_add(dt(src), src.shape[0], src.shape[1], _p(src), scale, group, gstride, off, _p(dst),
                                         st if st is not None else stream()), "csmae_rows_scatter_add")

@@ -331,6 +331,34 @@ __global__ __launch_bounds__(128) void rows_scatter_add_kernel(long long rows, i
     }
   }
 }
+// dst[view(r, off_a)] += scale_a * a[r] and dst[view(r, off_b)] += scale_b * b[r] in one pass (the cross-decoder head's two contributions to the
+// decoder-embedding gradient: - d/dv into the original's rows, the predictor's input gradient into the crop's — MAE_ViT_MsLdCeCd.py:56-59)
+template <typename T>
+__global__ __launch_bounds__(128) void rows_scatter_add2_kernel(long long rows, int D, const T* __restrict__ a, float sa, long long off_a, const T* __restrict__ b, float sb,
+                                                                long long off_b, long long group, long long gstride, float* __restrict__ dst) {
+  const int dv = D >> 2;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long long base = (r / group) * gstride + r % group;
+    float* da = dst + (base + off_a) * D;
+    float* db = dst + (base + off_b) * D;
+    for (int c = threadIdx.x; c < dv; c += blockDim.x) {
+      const f4_t va = ld4<T>(a + r * D + c * 4), vb = ld4<T>(b + r * D + c * 4);
+      const f4_t oa = *reinterpret_cast<f4_t*>(da + c * 4) + va * sa, ob = *reinterpret_cast<f4_t*>(db + c * 4) + vb * sb;
+      *reinterpret_cast<f4_t*>(da + c * 4) = oa;
+      *reinterpret_cast<f4_t*>(db + c * 4) = ob;
+    }
+  }
+}
+extern "C" int csmae_rows_scatter_add2(int dtype, long long rows, int D, const void* a, float scale_a, long long off_a, const void* b, float scale_b, long long off_b,
+                                       long long group, long long gstride, float* dst, void* stream) {
+  CSMAE_REQUIRE(rows > 0 && D % 4 == 0 && group > 0 && off_a != off_b, "csmae_rows_scatter_add2: bad geometry");
+  dim3 grid((unsigned)fmin((double)rows, 8192.0)), block(128);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CSMAE_BF16) hipLaunchKernelGGL((rows_scatter_add2_kernel<bf16_t>), grid, block, 0, st, rows, D, (const bf16_t*)a, scale_a, off_a, (const bf16_t*)b, scale_b, off_b, group, gstride, dst);
+  else if (dtype == CSMAE_F32) hipLaunchKernelGGL((rows_scatter_add2_kernel<float>), grid, block, 0, st, rows, D, (const float*)a, scale_a, off_a, (const float*)b, scale_b, off_b, group, gstride, dst);
+  else { csmae_set_error("csmae_rows_scatter_add2: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
+  return csmae_check_launch("csmae_rows_scatter_add2");
+}
 extern "C" int csmae_rows_gather(int dtype, long long rows, int D, const float* src, long long group, long long gstride, long long off, void* dst, void* stream) {
   CSMAE_REQUIRE(rows > 0 && D % 4 == 0 && group > 0, "csmae_rows_gather: bad geometry");
   dim3 grid((unsigned)fmin((double)rows, 4096.0)), block(128);

@@ -154,6 +154,11 @@ int csmae_rows_gather(int dtype, long long rows, int D, const float* src, long l
                       void* dst, void* stream);
 int csmae_rows_scatter_add(int dtype, long long rows, int D, const void* src, float scale, long long group, long long gstride,
                            long long off, float* dst, void* stream);
+/* two sources into two row views of the same buffer in one pass: dst[view(r) + off_a] += scale_a a[r], dst[view(r) + off_b] += scale_b b[r]
+ * (the cross-decoder loss' gradient w.r.t. its target — the original's decoder embedding — and the predictor's input gradient — the
+ * crop's —, MAE_ViT_MsLdCeCd.py:56-59: `loss_cd(x_embed_orig[:, 1:], predictor(x_embed_crop[:, 1:]))`, target not detached). */
+int csmae_rows_scatter_add2(int dtype, long long rows, int D, const void* a, float scale_a, long long off_a, const void* b, float scale_b, long long off_b,
+                            long long group, long long gstride, float* dst, void* stream);
 /* MAE_ViT_Shared.py:77 (`torch.gather(x, dim=1, index=ids_keep.unsqueeze(-1).repeat(1, 1, D))` of the stand-alone random_masking):
  * out[n, k, :] = x[n, ids[n * ids_ld + k], :], x [N, L, D] fp32, ids int32 (csmae_mask_sort's ids_keep), out [N, keep, D] fp32. */
 int csmae_rows_gather_idx(long long N, int L, int keep, int D, const float* x, const int* ids, long long ids_ld, float* out, void* stream);

@@ -422,14 +422,13 @@ def test_clip_grad_norm_with_user_frozen_parameters_stays_on_the_flat_buffer():
 
 def test_gradient_clear_on_the_side_stream_is_ordered_against_every_main_stream_writer(monkeypatch):
     """the flat gradient buffer is cleared on the weight-gradient stream while the reconstruction head's backward runs on the
-    main stream; main-stream writers into the buffer wait for that clear through ONE event.  A writer placed above the wait would race it:
-    the whole buffer must be bit-identical to the run whose clear sits on the main stream (CSMAE_ZERO_MAIN=1), step after step."""
+    main stream; main-stream writers into the buffer wait for that clear through ONE event.  A writer placed above the wait would race it
+    and lose its contribution: the whole buffer must match the run whose clear sits on the main stream (CSMAE_ZERO_MAIN=1), step after
+    step — bit for bit where the step is bit-reproducible at this geometry (checked first: two default runs), to rounding otherwise."""
     from csmae_hip.engine import FlatParams
     x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).cuda()
-    outs = {}
-    for mode in ("side", "main"):
-        if mode == "main":
-            monkeypatch.setenv("CSMAE_ZERO_MAIN", "1")
+
+    def run():
         m = _cecd()
         m.compute_dtype = torch.bfloat16
         snaps = []
@@ -438,9 +437,17 @@ def test_gradient_clear_on_the_side_stream_is_ordered_against_every_main_stream_
             m.zero_grad(set_to_none=True)
             m(x)[0].backward()
             snaps.append(FlatParams.owner_of(m.decoder_pred.weight).g.clone())
-        outs[mode] = snaps
-    for a, b in zip(outs["side"], outs["main"]):
-        assert torch.equal(a, b)
+        return snaps
+    side, side2 = run(), run()
+    monkeypatch.setenv("CSMAE_ZERO_MAIN", "1")
+    main = run()
+    reproducible = all(torch.equal(a, b) for a, b in zip(side, side2))
+    for a, b in zip(side, main):
+        if reproducible:
+            assert torch.equal(a, b)
+        else:   # (small shapes take kernels whose reduction order is not fixed: a lost contribution is orders of magnitude above that noise)
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 1e-3 * scale, (float((a - b).abs().max()), scale)
 
 
 def test_non_finite_loss_never_reaches_the_weights():
