@@ -23,5 +23,8 @@ for p in large large4; do timeout 600 python bench.py --preset $p --steps 5 --wa
 for d in bf16 fp8; do timeout 600 python bench.py --preset huge14 --dtype $d --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out/bench_presets.txt; done
 cp $out/pmc_traffic.json profiles/pmc_traffic.json   # (on the GPU box only: the bench line below then carries roofline.traffic for these sources; copy it into profiles/ by hand afterwards)
 timeout 600 python bench.py 2>/dev/null | tail -1 > $out/bench_final.json
-timeout 400 python tools/graph_probe.py 2>&1 | grep -E "^eager|^graph|^captured|^loss" > $out/graph_vs_eager.txt
-cut -c1-300 $out/bench_default.json; head -4 $out/pmc_hbm_traffic.txt; cat $out/graph_vs_eager.txt
+# per-kernel table of the fp8 step (BASELINE.json configs[4]: ViT-H/14, 256 per GPU, fp8 MFMA GEMMs), taken on the same sources
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/proff8_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --preset huge14 --dtype fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
+python tools/rocpd_stats.py $(find /tmp/proff8_$tag -name '*.db' | head -1) $out/huge14_fp8_kernel_stats.txt > /dev/null
+[ -n "$GRAPH_PROBE" ] && timeout 400 python tools/graph_probe.py 2>&1 | grep -E "^eager|^graph|^captured|^loss" > $out/graph_vs_eager.txt
+cut -c1-300 $out/bench_default.json; head -4 $out/pmc_hbm_traffic.txt
