@@ -330,6 +330,7 @@ struct AttnBwd1p {
   static constexpr int NP = NKF / 2, TP = NKF * 16, IMG = TP * AttnLds<HD>::STRIDE, QS = HD + 4;
   static constexpr int XB = 32 * HD * 2;  // per wave: 4 dS tiles (bf16 [16 keys][16 queries]) or the wave's 32 K rows
   static constexpr int LDS = 2 * IMG + TP * QS * 4 + 4 * XB + 2 * TP * 4;
+  static constexpr int LDS8 = LDS + 4 * XB;   // eight-wave form of attn_bwd1p_bf16: eight patches
 };
 template <int HD>  // transposed fragment from an unpadded [rows][HD] bf16 patch (same k order as frag_cols_tr)
 __device__ __forceinline__ s8_t patch_cols_tr(const char* img, int c0, int t, int g) {
@@ -346,17 +347,22 @@ extern "C" int csmae_debug_attn_ts(unsigned long long* out) { return (int)hipMem
 #else
 #define TS(i)
 #endif
-template <int HD, int NKF, bool EMIT = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+// NW = 8 (512 threads, one workgroup per CU): for sequences of nine key pairs and more (257 tokens: ViT-L/16 at 256^2, ViT-H/14 — BASELINE.json
+// configs[3] / [4]).  Their head image (98 KiB at head_dim 32) admits ONE workgroup per CU whatever its width, and four waves walked the query
+// pairs three times (pairs w, w + 4, w + 8: 27 barrier-separated steps, the third sweep with one busy wave): eight waves walk them twice
+// (18 steps) with twice the waves in flight.  The rotation (wave w updates query pair (w + s) mod nq in step s) needs NW <= nq.
+template <int HD, int NKF, bool EMIT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_bwd1p_bf16(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, int T, int H, int D, int hd, float scale, Fp8Emit em) {
   using L = AttnBwd1p<HD, NKF>;
   constexpr int TP = L::TP, NP = L::NP, KS = HD / 32, DF = HD / 16, IMG = L::IMG, QS = L::QS;
-  __shared__ __attribute__((aligned(16))) char smem[L::LDS];
+  static_assert(NW == 4 || (NW == 8 && NP >= 8), "eight waves need at least eight query pairs for the dQ rotation");
+  __shared__ __attribute__((aligned(16))) char smem[NW == 4 ? L::LDS : L::LDS8];
   char* Qs = smem; char* Gs = smem + IMG;                                // Gs = dO
   float* dqa = reinterpret_cast<float*>(smem + 2 * IMG);                 // dQ accumulator [TP][QS]
   char* xall = smem + 2 * IMG + TP * QS * 4;
-  float* lse2 = reinterpret_cast<float*>(xall + 4 * L::XB);              // log2-domain LSE, +inf on padded rows
+  float* lse2 = reinterpret_cast<float*>(xall + NW * L::XB);             // log2-domain LSE, +inf on padded rows
   float* dl = lse2 + TP;                                                 // D_i = sum_d dO_i . O_i
   const int wid = pair_remap<HD>(blockIdx.x, gridDim.x);
   const int b = wid / H, h = wid - b * H;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   float qmax = 0.f, qseen = 0.f;
   const float qs = EMIT ? fp8_emit_scale(em, lane, qmax) : 1.f;   // (EMIT: the fp8 copy of dqkv, see attn_fwd_bf16)
   TS(0);
-  HeadStager<HD, TP, 256, 2> sg;
+  HeadStager<HD, TP, NW * 64, 2> sg;
   sg.load(0, qkv, row0, ld, h * hd, T, hd); sg.load(1, dout, row0, D, h * hd, T, hd);
   // K / V rows of a wave's key pair, straight from global memory.  The loads of sweep 0 go out with the staging loads above, those
   // of the next sweep right after a sweep's first barrier: their latency (4k clk each, measured) stays off the critical path.
@@ -414,8 +420,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
   const float c2 = scale * LOG2E;
   char* xw = xall + w * L::XB;              // this wave's patch
   const int nq = (T + 31) >> 5;             // query-tile pairs that hold real rows
-  for (int sweep = 0; sweep * 4 < nkp; ++sweep) {
-    const int kp = sweep * 4 + w;
+  for (int sweep = 0; sweep * NW < nkp; ++sweep) {
+    const int kp = sweep * NW + w;
     const bool active = kp < nkp;           // (wave-uniform) the last sweep may have fewer pairs than waves
     const int k0 = 32 * kp;
     // K, V rows of the two key tiles straight from global memory; K^T (k = keys) through the patch
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1p_bf16(const bf16_t* __restri
     TS(2 + 4 * sweep);
     __syncthreads();                        // (first sweep: staging visible; later sweeps: previous sweep's last dQ update done)
     TS(3 + 4 * sweep);
-    if ((sweep + 1) * 4 < nkp) load_kv((sweep + 1) * 4 + w);
+    if ((sweep + 1) * NW < nkp) load_kv((sweep + 1) * NW + w);
     for (int s = 0; s < nq; ++s) {
       int ip = w + s; if (ip >= nq) ip -= nq;
       const int q0 = 32 * ip;
@@ -931,10 +937,17 @@ static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void
   static const bool two_sweeps = getenv("CSMAE_ATTN_BWD_2SWEEP") != nullptr;  // tuning aid: one key pair per wave and sweep (the first single-pass version)
   constexpr bool KP2_OK = HD <= 32 && NKF >= 6 && NKF <= 16 && AttnBwd1p<HD, NKF>::LDS <= 160 * 1024;
   constexpr int NK1 = AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2;
+  constexpr bool W8_OK = NKF >= 18 && AttnBwd1p<HD, NKF>::LDS8 <= 160 * 1024;
+  static const bool four_waves = getenv("CSMAE_ATTN_BWD_4WAVES") != nullptr;   // tuning aid: the four-wave form for long sequences as well
 #define ATTN_BWD_ARGS (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale
   if (KP2_OK && !two_pass && !two_sweeps) {
     if (em) CSMAE_LAUNCH((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2), true>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, *em);
     else CSMAE_LAUNCH((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2), false>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, Fp8Emit{});
+  } else if (W8_OK && !two_pass && !four_waves) {   // nine key pairs and more (257 tokens): eight waves, two sweeps
+    if constexpr (W8_OK) {
+      if (em) CSMAE_LAUNCH((attn_bwd1p_bf16<HD, NKF, true, 8>), dim3(BH), dim3(512), 0, st, ATTN_BWD_ARGS, *em);
+      else CSMAE_LAUNCH((attn_bwd1p_bf16<HD, NKF, false, 8>), dim3(BH), dim3(512), 0, st, ATTN_BWD_ARGS, Fp8Emit{});
+    }
   } else if (AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 && NKF >= 6 && !two_pass) {  // (<= 64 tokens: fewer key pairs than waves, the two-pass split is faster)
     if (em) CSMAE_LAUNCH((attn_bwd1p_bf16<HD, NK1, true>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, *em);
     else CSMAE_LAUNCH((attn_bwd1p_bf16<HD, NK1, false>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, Fp8Emit{});

@@ -10,112 +10,96 @@
 // ------------------------------------------------------------------------------------------ crop + AA bilinear resize
 // Follows ATen's separable anti-aliased bilinear filter (triangle filter, support = max(scale, 1), weights
 // renormalised), horizontal pass first, in float.  `box` = device int[4] {top i, left j, height h, width w}.
-struct AxisTaps { int lo, n; float w[8]; };
-__device__ __forceinline__ void aa_taps(int o, int in_size, int out_size, AxisTaps& tp) {
+// A workgroup = CROP_ROWS output rows of one plane, a thread = one output column of them, no LDS, no barrier.  The crop of the step always
+// up-samples (the box is a part of the image: support 1, at most 3 taps per axis): a thread computes its column's taps ONCE for the strip's
+// rows, the rows' taps are computed by the first CROP_ROWS lanes of every wave (one row each) and handed to all lanes as scalars
+// (v_readlane), and the <= 9 source pixels of an output come straight from global memory, where neighbouring outputs share them (L1 / L2).
+// History: tap tables in LDS per workgroup + three barrier-separated LDS phases (two dependent global round trips per workgroup at four
+// workgroups per CU): 92-110 us for 154 MB; one thread per pixel with both axes' taps per thread: 129 us (~400 instructions per pixel, the
+// divisions of the weight normalisation).  Boxes larger than the output (down-sampling: up to 8 taps per axis, as ATen's kernel) take
+// the per-pixel loop form: same sums in the same order.
+#define CROP_ROWS 8
+struct AxisRange { float center, inv; int lo, n; float tot; };
+__device__ __forceinline__ float aa_w(const AxisRange& r, int k) { const float a = fabsf((k + r.lo - r.center + 0.5f) * r.inv); return a < 1.f ? 1.f - a : 0.f; }
+__device__ __forceinline__ AxisRange aa_range(int o, int in_size, int out_size) {
+  AxisRange r;
   const float scale = (float)in_size / (float)out_size;
   const float support = scale >= 1.f ? scale : 1.f;
-  const float inv = scale >= 1.f ? 1.f / scale : 1.f;
-  const float center = scale * (o + 0.5f);
-  int lo = (int)(center - support + 0.5f); lo = lo < 0 ? 0 : lo;
-  int hi = (int)(center + support + 0.5f); hi = hi > in_size ? in_size : hi;
+  r.inv = scale >= 1.f ? 1.f / scale : 1.f;
+  r.center = scale * (o + 0.5f);
+  int lo = (int)(r.center - support + 0.5f); lo = lo < 0 ? 0 : lo;
+  int hi = (int)(r.center + support + 0.5f); hi = hi > in_size ? in_size : hi;
   int n = hi - lo; n = n > 8 ? 8 : n;
+  r.lo = lo; r.n = n;
   float tot = 0.f;
-  for (int k = 0; k < n; ++k) { float a = fabsf((k + lo - center + 0.5f) * inv); float w = a < 1.f ? 1.f - a : 0.f; tp.w[k] = w; tot += w; }
-  for (int k = 0; k < n; ++k) tp.w[k] /= tot;
-  tp.lo = lo; tp.n = n;
+  for (int k = 0; k < n; ++k) tot += aa_w(r, k);
+  r.tot = tot;
+  return r;
 }
-// One workgroup = CROP_ROWS output rows of one plane.  The tap tables of the S output columns and of the workgroup's rows are built once
-// in LDS (the first version rebuilt them per thread and kept them in a dynamically indexed private array, i.e. in scratch memory).
-// When the source rows those output rows touch fit the LDS budget (always when up-sampling: <= CROP_ROWS + 3 rows; 32 rows per workgroup measured slower: 120 vs 97 us), the filter runs
-// separably on them: along W once per source row into LDS, then along H per output row — the same sums in the same order as the
-// direct form (a row's horizontal sum does not depend on which output row uses it), with every source pixel fetched once.
-#define CROP_ROWS 8
-#define CROP_SRC_ROWS 16
-__global__ __launch_bounds__(256) void crop_resize_kernel(long long planes, int S, const float* __restrict__ src, float* __restrict__ dst,
-                                                          const int* __restrict__ box) {
-  extern __shared__ int crop_lds[];
-  int* xlo = crop_lds; int* xn = xlo + S; float* xw = reinterpret_cast<float*>(xn + S);          // [S], [S], [8][S]
-  int* ylo = reinterpret_cast<int*>(xw + S * 8); int* yn = ylo + CROP_ROWS; float* yw = reinterpret_cast<float*>(yn + CROP_ROWS);  // [R], [R], [R][8]
-  float* hs = yw + CROP_ROWS * 8;                                                                 // [CROP_SRC_ROWS][S] horizontal sums
+__global__ __launch_bounds__(256) void crop_resize_kernel(int S, const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ box) {
   const int bi = box[0], bj = box[1], bh = box[2], bw = box[3];
-  const int oy0 = blockIdx.x * CROP_ROWS;
+  const int oy0 = blockIdx.x * CROP_ROWS, lane = threadIdx.x & 63;
   const long long pl = blockIdx.y;
-  for (int i = threadIdx.x; i < S + CROP_ROWS; i += blockDim.x) {
-    AxisTaps t;
-    const bool isx = i < S;
-    aa_taps(isx ? i : min(oy0 + i - S, S - 1), isx ? bw : bh, S, t);
-    int* lo = isx ? xlo + i : ylo + (i - S); int* n = isx ? xn + i : yn + (i - S);
-    float* w = isx ? xw + i : yw + (i - S) * 8; const int ws = isx ? S : 1;   // x taps tap-major ([8][S]: lanes read consecutive banks)
-    *lo = t.lo; *n = t.n;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k * ws] = k < t.n ? t.w[k] : 0.f;
-  }
-  __syncthreads();
   const float* plane = src + pl * S * S;
-  const int rows = min(CROP_ROWS, S - oy0);
-  const int y_first = ylo[0], y_last = ylo[rows - 1] + yn[rows - 1];   // source rows [y_first, y_last) relative to the box (monotone in oy)
-  const int nsrc = y_last - y_first;
-  if (nsrc <= CROP_SRC_ROWS) {
-    // The source pixels these output rows touch — nsrc rows of the box, its bw columns — are first staged in LDS by whole 16-byte loads that
-    // are independent of each other (the filter loops below have data-dependent trip counts: read straight from global memory they were a
-    // chain of dependent gathers, 1.66 TB/s); both filter passes then run out of LDS.
-    float* tile = hs + CROP_SRC_ROWS * S;                               // [CROP_SRC_ROWS][tw], tw = columns from the aligned start
-    const int c0 = (S & 3) == 0 ? (bj & ~3) : bj;                        // (16-byte aligned column when the plane rows are)
-    const int tw = ((bj + bw - c0) + 3) & ~3;                            // <= S + 3
-    const int ts = S + 4;
-    if ((S & 3) == 0) {
-      const int q = tw >> 2;
-      for (int i = threadIdx.x; i < nsrc * q; i += blockDim.x) {
-        const int a = i / q, c = (i - a * q) * 4;
-        f4_t v = {0.f, 0.f, 0.f, 0.f};
-        if (c0 + c + 3 < S) v = *reinterpret_cast<const f4_t*>(plane + (long long)(bi + y_first + a) * S + c0 + c);
-        else for (int k = 0; k < 4; ++k) if (c0 + c + k < S) v[k] = plane[(long long)(bi + y_first + a) * S + c0 + c + k];
-        *reinterpret_cast<f4_t*>(tile + a * ts + c) = v;
-      }
-    } else {
-      for (int i = threadIdx.x; i < nsrc * tw; i += blockDim.x) {
-        const int a = i / tw, c = i - a * tw;
-        tile[a * ts + c] = c0 + c < S ? plane[(long long)(bi + y_first + a) * S + c0 + c] : 0.f;
-      }
-    }
-    __syncthreads();
-    const int shift = bj - c0;
-    for (int i = threadIdx.x; i < nsrc * S; i += blockDim.x) {
-      const int a = i / S, ox = i - a * S;
-      const float* base = tile + a * ts + shift + xlo[ox];
-      const int nx = xn[ox];
-      float hsum = 0.f;
-      for (int b = 0; b < nx; ++b) hsum += xw[b * S + ox] * base[b];
-      hs[a * S + ox] = hsum;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < rows * S; i += blockDim.x) {
-      const int r = i / S, ox = i - r * S;
-      const int ny = yn[r], a0 = ylo[r] - y_first;
+  float* out = dst + pl * S * S;
+  if (bw > S || bh > S) {   // down-sampling (not the step's case): per-pixel loops
+    for (int i = threadIdx.x; i < CROP_ROWS * S; i += 256) {
+      const int r = i / S, ox = i - r * S, oy = oy0 + r;
+      if (oy >= S) break;
+      const AxisRange rx = aa_range(ox, bw, S), ry = aa_range(oy, bh, S);
+      const float* base = plane + (long long)(bi + ry.lo) * S + bj + rx.lo;
       float acc = 0.f;
-      for (int a = 0; a < ny; ++a) acc += yw[r * 8 + a] * hs[(a0 + a) * S + ox];
-      dst[pl * S * S + (long long)(oy0 + r) * S + ox] = acc;
+      for (int a = 0; a < ry.n; ++a) {
+        float hsum = 0.f;
+        for (int b = 0; b < rx.n; ++b) hsum += (aa_w(rx, b) / rx.tot) * base[a * S + b];
+        acc += (aa_w(ry, a) / ry.tot) * hsum;
+      }
+      out[(long long)oy * S + ox] = acc;
     }
     return;
   }
-  for (int i = threadIdx.x; i < rows * S; i += blockDim.x) {   // (strong down-sampling: direct form)
-    const int r = i / S, ox = i - r * S, oy = oy0 + r;
-    const int ny = yn[r], nx = xn[ox];
-    const float* base = plane + (long long)(bi + ylo[r]) * S + bj + xlo[ox];
-    float acc = 0.f;
-    for (int a = 0; a < ny; ++a) {
-      float hsum = 0.f;
-      for (int b = 0; b < nx; ++b) hsum += xw[b * S + ox] * base[a * S + b];
-      acc += yw[r * 8 + a] * hsum;
+  // rows' taps: lane r < CROP_ROWS of every wave computes those of row oy0 + r
+  const AxisRange ry = aa_range(min(oy0 + min(lane, CROP_ROWS - 1), S - 1), bh, S);
+  float wyl[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) wyl[k] = k < ry.n ? aa_w(ry, k) / ry.tot : 0.f;
+  for (int ox = threadIdx.x; ox < S; ox += 256) {   // (one trip for S <= 256)
+    const AxisRange rx = aa_range(ox, bw, S);
+    float wx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wx[k] = k < rx.n ? aa_w(rx, k) / rx.tot : 0.f;
+    const float* col = plane + (long long)bi * S + bj + rx.lo;
+#pragma unroll
+    for (int r = 0; r < CROP_ROWS; ++r) {
+      const int oy = oy0 + r;
+      if (oy >= S) break;
+      const int ylo = __builtin_amdgcn_readlane(ry.lo, r), yn = __builtin_amdgcn_readlane(ry.n, r);
+      const float wy0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyl[0]), r));
+      const float wy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyl[1]), r));
+      const float wy2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyl[2]), r));
+      const float wy[3] = {wy0, wy1, wy2};
+      const float* base = col + (long long)ylo * S;
+      float v[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) v[a][b] = (a < yn && b < rx.n) ? base[a * S + b] : 0.f;   // (all loads in flight before the first use)
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        float hsum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) if (b < rx.n) hsum += wx[b] * v[a][b];
+        if (a < yn) acc += wy[a] * hsum;
+      }
+      out[(long long)oy * S + ox] = acc;
     }
-    dst[pl * S * S + (long long)oy * S + ox] = acc;
   }
 }
 extern "C" int csmae_crop_resize(long long planes, int S, const float* src, float* dst, const int* box, void* stream) {
   CSMAE_REQUIRE(planes > 0 && planes < 65536 && S > 0 && S <= 1024 && src && dst && box, "csmae_crop_resize: bad args");
   dim3 grid((S + CROP_ROWS - 1) / CROP_ROWS, (unsigned)planes), block(256);
-  const size_t lds = ((size_t)(S + CROP_ROWS) * 10 + (size_t)CROP_SRC_ROWS * S + (size_t)CROP_SRC_ROWS * (S + 4)) * sizeof(float);
-  hipLaunchKernelGGL(crop_resize_kernel, grid, block, lds, (hipStream_t)stream, planes, S, src, dst, box);
+  hipLaunchKernelGGL(crop_resize_kernel, grid, block, 0, (hipStream_t)stream, S, src, dst, box);
   return csmae_check_launch("csmae_crop_resize");
 }
 
