@@ -941,15 +941,17 @@ class Engine:
             ops.ssim_bwd(ssim[1], ws.pred, ws.mask, ws.gout, sv["rscale"] * ssim[2], ws.ssim_ws, extra, B2, N, c["C"], c["S"], c["p"], st=st)
         ops.recon_loss_bwd(kind, npx, sv["img0"], sv["img1"], ws.pred, sv["mm"], ws.mask, ws.losses, ws.gout, sv["rscale"], ws.dpred_lp,
                            B2, N, c["C"], c["S"], c["p"], extra=extra, st=st)
-        self._dw(ws.dpred_lp, ws.emb_lp, "decoder_pred")
+        timed = ops._timer is not None or bool(os.environ.get("CSMAE_DW_MAIN"))
+        heads_serial = timed or not self.has_pred or bool(os.environ.get("CSMAE_HEADS_BWD_SERIAL"))
+        if heads_serial or os.environ.get("CSMAE_DW_EAGER"):   # (otherwise: with the predictor's weight gradients, once the junction is over — below)
+            self._dw(ws.dpred_lp, ws.emb_lp, "decoder_pred")
         ops.gemm(ws.dpred_lp, self._w_pred(), ws.demb, trans_b=True, st=st)
         if zeroed is not None:
             self.main.wait_event(zeroed)
         if self.has_pred:
             kcd = c["loss_cd"]
             bn = "predictor.1."
-            timed = ops._timer is not None or bool(os.environ.get("CSMAE_DW_MAIN"))
-            if timed or os.environ.get("CSMAE_HEADS_BWD_SERIAL"):   # (one chain on the main stream: per-kernel timing, A/B aid)
+            if heads_serial:   # (one chain on the main stream: per-kernel timing, A/B aid)
                 ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
                                   da_lp=ws.dv, dt_acc=ws.demb, st=st)
                 self._dw(ws.dv, ws.r, "predictor.3")
@@ -970,17 +972,21 @@ class Engine:
                     aux.wait_event(zeroed)                   # (BatchNorm's parameter gradients go straight into the flat buffer)
                 ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
                                   da_lp=ws.dv, st=ast)
-                e1 = self._event()
-                e1.record(aux)
-                self._dw_group([(ws.dv, ws.r, "predictor.3")], ready=e1)
                 ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=ast)
                 ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=ast)
-                e2 = self._event()
-                e2.record(aux)
-                self._dw_group([(ws.dr, ws.pin, "predictor.0")], ready=e2)
                 ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=ast)
                 self.main.wait_stream(aux)
                 ops.rows_scatter_add2(ws.dv, -1.0, 1, ws.dpin, 1.0, N * Td + 1, ws.demb, L, Td, st=st)
+                # the heads' weight-gradient launches wait for the junction to be over (an event behind the combining kernel): started as soon
+                # as their operands exist, their 160 workgroups each took the CUs this chain — the longest of the junction — was running on
+                # (CSMAE_DW_EAGER=1: as early as possible, A/B aid)
+                if os.environ.get("CSMAE_DW_EAGER"):
+                    ej = None
+                else:
+                    ej = self._event()
+                    ej.record(self.main)
+                    self._dw_group([(ws.dpred_lp, ws.emb_lp, "decoder_pred")], ready=ej)
+                self._dw_group([(ws.dv, ws.r, "predictor.3"), (ws.dr, ws.pin, "predictor.0")], ready=ej)
         # decoder
         lp_stream = self.res_dtype != torch.float32   # bf16 residual-gradient stream: the ping-pong buffers are the stream itself
         pd, Nd2 = ws.ln_part_d, 2 * c["Nd"]
