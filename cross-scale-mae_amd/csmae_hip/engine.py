@@ -155,7 +155,7 @@ class Workspace:
         self.dn_st = E(2, Md, **f32)
         # decoder_pred's output: bf16 in throughput mode (what autocast hands the reference's loss; the reconstruction head reads it twice and the
         # product writes it once: 155 -> 77 MB each), fp32 in parity mode and for the ssim family (its kernels take fp32 planes)
-        self.pred = E(Md, c["P"], **(lp if (T != torch.float32 and c["loss"] not in SSIM_KINDS and c["P"] % 8 == 0 and not os.environ.get("CSMAE_PRED_FP32")) else f32))
+        self.pred = E(Md, c["P"], **(lp if (T != torch.float32 and c["loss"] not in SSIM_KINDS and c["P"] % 8 == 0) else f32))
         self.rowloss = E(B2 * L, **f32)
         self.minmax = E(4, **f32)
         self.mm_scratch = E(B2 * L * 2, **f32) if c["loss"] == "bce" else None
@@ -241,7 +241,7 @@ class Engine:
         # residual epilogues, LayerNorm forward / backward and the stack boundaries move half the bytes (they are HBM- / store-bound,
         # DESIGN §4).  CSMAE_RESID_FP32=1 keeps the fp32 stream under the bf16 GEMMs (what torch autocast does; A/B aid).
         self.res_dtype = torch.float32 if (self.T == F32 or os.environ.get("CSMAE_RESID_FP32")) else torch.bfloat16
-        self.gp_q8 = self.T == BF16 and not os.environ.get("CSMAE_GP_BF16")   # gelu' saved as 8-bit codes (csmae.h CSMAE_EPI_GELU_Q8); env: A/B aid
+        self.gp_q8 = self.T == BF16   # gelu' saved as 8-bit codes (csmae.h CSMAE_EPI_GELU_Q8)
         v = cfg["variant"]
         self.views = 1 if v == "Baseline" else 2
         self.has_pred = v in ("MsLdCd", "MsLdLeCd", "MsLdCeCd")
@@ -264,8 +264,6 @@ class Engine:
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
-        self._ev_carry = os.environ.get("CSMAE_EV_CARRY", "1") != "0"   # A/B aid: 0 = events recorded behind the kernels, as before
-        self._fwd_lead = int(os.environ.get("CSMAE_FWD_LEAD", "0"))   # samples the main stream's forward chunk takes beyond half of the batch
         self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
         # 128 workgroups = 4 / 8 whole K slices of its 32- and 16-tile launches (160 -> 128: -0.15 .. -0.3 ms per step; 64: +1.4 ms)
@@ -556,7 +554,7 @@ class Engine:
         ed = self._emit(kd, ws.q_b[0], M, 4 * Dm, 1) if self.fp8 else None
         # the kernels whose outputs a weight-gradient launch waits for carry that launch's event themselves (an event recorded behind them
         # is a marker packet: ~5 us of idle main stream each, two per block)
-        carried = self._ev_carry and ops._timer is None and not os.environ.get("CSMAE_DW_MAIN")
+        carried = ops._timer is None and not os.environ.get("CSMAE_DW_MAIN")
         ev1 = self._event() if (carried and mode == "half") else None
         with (ops.launch_done(ev1, st) if ev1 is not None else contextlib.nullcontext()):
             self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
@@ -628,11 +626,7 @@ class Engine:
         self._fp8_begin()
         img0 = imgs
         two = self.views == 2 and ops._timer is None and not os.environ.get("CSMAE_FWD_ONE_STREAM")
-        nch = int(os.environ.get("CSMAE_FWD_CHUNKS", "2"))  # tuning aid: independent sample chunks in flight (2 = one per view)
-        if nch < 2 or B2 % nch:
-            nch = 2
-        lead = self._fwd_lead if (two and nch == 2 and not self.fp8 and 0 < B2 // nch + self._fwd_lead < B2) else 0   # (fp8: the staging buffers of a chunk hold half a batch)
-        chunk_is_view = two and nch == 2 and lead == 0
+        nch = 2   # sample chunks in flight on their own streams: one per view (4 / 8 chunks and an uneven split were measured and lost)
         # (The stem per view on the view's stream — the original's patches not waiting for the crop kernel — measured neutral: 21.87 vs 21.88 ms,
         # the original's patch-embed product queues behind the crop kernel's 10 k workgroups for CUs anyway.  One stem on the main stream.)
         if self.views != 2:
@@ -663,7 +657,7 @@ class Engine:
         # cross-decoder predictor (MAE_ViT_MsLdCeCd.py:57: gather -> Linear -> BatchNorm/ReLU -> Linear) only the crop's decoder output —
         # they run behind their trunk instead of behind the join of both (where one stream idles until the other arrives).  Only when a
         # chunk IS a view and the per-patch kind needs no whole-tensor statistics (bce's min / max, the ssim family).
-        view_heads = chunk_is_view and ssim is None and kind in ("mse", "l2", "mae", "l1") and not os.environ.get("CSMAE_HEADS_JOINED")
+        view_heads = two and ssim is None and kind in ("mse", "l2", "mae", "l1")
 
         emb_ready = []
 
@@ -721,9 +715,7 @@ class Engine:
             while len(self._fwd_streams) < nch - 1:
                 self._fwd_streams.append(self.side if (not self._fwd_streams and not getattr(self, "_side_masked", False)) else torch.cuda.Stream())
             per = B2 // nch
-            # the main stream starts first (the other ones wait for the stem) and would idle at the join: it takes `_fwd_lead` samples more
-            # than its share (chunks are sample ranges: attention, LayerNorm and the GEMM rows do not care where a view ends)
-            cuts = [0, per + lead] + [k * per for k in range(2, nch)] + [B2]
+            cuts = [k * per for k in range(nch)] + [B2]
             for so in self._fwd_streams[: nch - 1]:
                 so.wait_stream(main)         # (the stem; and the previous step's readers of the workspace)
             if self.has_ce:
@@ -731,17 +723,12 @@ class Engine:
                                              # enqueued: the contrastive branch then starts when both encoders are done, under the decoders' GEMMs
             evs = []
             # which chunk the main stream takes: with the per-view heads the CROP's (the last chunk) — the main stream starts first and tends to
-            # finish first, and the predictor that follows the crop's decoder is the longest tail of the forward pass (CSMAE_FWD_SWAP=0: the original's)
+            # finish first, and the predictor that follows the crop's decoder is the longest tail of the forward pass (-0.09 ms against the original's)
             order = list(range(nch))
-            if view_heads and self.has_pred and os.environ.get("CSMAE_FWD_SWAP", "1") != "0":
+            if view_heads and self.has_pred:
                 order = [nch - 1] + list(range(nch - 1))
             lanes = [(st, main)] + [(so.cuda_stream, so) for so in self._fwd_streams[: nch - 1]]
             gens = [trunk(cuts[k], cuts[k + 1] - cuts[k], lanes[i][0], lanes[i][1], evs) for i, k in enumerate(order)]
-            if os.environ.get("CSMAE_FWD_SEQ_ENQUEUE"):  # tuning aid: one trunk after the other, as before
-                for g in gens:
-                    for _ in g:
-                        pass
-                gens = []
 
             def contrastive():
                 for ev in evs:
@@ -942,8 +929,8 @@ class Engine:
         ops.recon_loss_bwd(kind, npx, sv["img0"], sv["img1"], ws.pred, sv["mm"], ws.mask, ws.losses, ws.gout, sv["rscale"], ws.dpred_lp,
                            B2, N, c["C"], c["S"], c["p"], extra=extra, st=st)
         timed = ops._timer is not None or bool(os.environ.get("CSMAE_DW_MAIN"))
-        heads_serial = timed or not self.has_pred or bool(os.environ.get("CSMAE_HEADS_BWD_SERIAL"))
-        if heads_serial or os.environ.get("CSMAE_DW_EAGER"):   # (otherwise: with the predictor's weight gradients, once the junction is over — below)
+        heads_serial = timed or not self.has_pred
+        if heads_serial:   # (otherwise: with the predictor's weight gradients, once the junction is over — below)
             self._dw(ws.dpred_lp, ws.emb_lp, "decoder_pred")
         ops.gemm(ws.dpred_lp, self._w_pred(), ws.demb, trans_b=True, st=st)
         if zeroed is not None:
@@ -979,13 +966,10 @@ class Engine:
                 ops.rows_scatter_add2(ws.dv, -1.0, 1, ws.dpin, 1.0, N * Td + 1, ws.demb, L, Td, st=st)
                 # the heads' weight-gradient launches wait for the junction to be over (an event behind the combining kernel): started as soon
                 # as their operands exist, their 160 workgroups each took the CUs this chain — the longest of the junction — was running on
-                # (CSMAE_DW_EAGER=1: as early as possible, A/B aid)
-                if os.environ.get("CSMAE_DW_EAGER"):
-                    ej = None
-                else:
-                    ej = self._event()
-                    ej.record(self.main)
-                    self._dw_group([(ws.dpred_lp, ws.emb_lp, "decoder_pred")], ready=ej)
+                # (22.19 vs 22.22 ms: within the noise, kept for the shorter junction)
+                ej = self._event()
+                ej.record(self.main)
+                self._dw_group([(ws.dpred_lp, ws.emb_lp, "decoder_pred")], ready=ej)
                 self._dw_group([(ws.dv, ws.r, "predictor.3"), (ws.dr, ws.pin, "predictor.0")], ready=ej)
         # decoder
         lp_stream = self.res_dtype != torch.float32   # bf16 residual-gradient stream: the ping-pong buffers are the stream itself
