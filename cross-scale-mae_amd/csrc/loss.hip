@@ -343,8 +343,9 @@ extern "C" int csmae_pair_loss_bwd(int kind, int lp_dtype, long long rows, int D
   CSMAE_REQUIRE(kind >= LOSS_MSE && kind <= LOSS_L1, "csmae_pair_loss: kind %d unsupported for un-masked pair losses (mse/l2/mae/l1 only)", kind);
   RowView va{a_group, a_gstride, a_off}, vt{t_group, t_gstride, t_off};
   hipStream_t st = (hipStream_t)stream;
-  if (lp_dtype == CSMAE_BF16) hipLaunchKernelGGL((pair_bwd_kernel<bf16_t>), dim3(2048), dim3(128), 0, st, kind, rows, D, a, va, t, vt, gout, coef, (bf16_t*)da_lp, da_acc, dt_acc);
-  else hipLaunchKernelGGL((pair_bwd_kernel<float>), dim3(2048), dim3(128), 0, st, kind, rows, D, a, va, t, vt, gout, coef, (float*)da_lp, da_acc, dt_acc);
+  const dim3 grid((unsigned)(rows < 8192 ? rows : 8192));   // (2 048 workgroups walked 12 rows each one after the other: 1.5-2.5 TB/s; every CU's share resident at once)
+  if (lp_dtype == CSMAE_BF16) hipLaunchKernelGGL((pair_bwd_kernel<bf16_t>), grid, dim3(128), 0, st, kind, rows, D, a, va, t, vt, gout, coef, (bf16_t*)da_lp, da_acc, dt_acc);
+  else hipLaunchKernelGGL((pair_bwd_kernel<float>), grid, dim3(128), 0, st, kind, rows, D, a, va, t, vt, gout, coef, (float*)da_lp, da_acc, dt_acc);
   return csmae_check_launch("csmae_pair_loss_bwd");
 }
 
@@ -471,6 +472,48 @@ __global__ __launch_bounds__(1024) void ntx_bwd_kernel(int N, int D, const float
   const float inv = inv_norm[i];
   for (int d = threadIdx.x; d < D; d += blockDim.x) dpool[(long long)i * D + d] = (dpool[(long long)i * D + d] - z[(long long)i * D + d] * dot) * inv;
 }
+// The same for D % 4 == 0, D <= 4096: 16-byte columns, the 2N-long walk split over G = 1024 / (D / 4) groups of threads with four loads in flight
+// each, folded through LDS in group order (the first form: one 4-byte column per thread, 2N dependent-latency trips; it sits on the main
+// chain between the decoder's and the encoder's backward).
+__global__ __launch_bounds__(1024) void ntx_bwd4_kernel(int N, int D, const float* __restrict__ z, const float* __restrict__ inv_norm,
+                                                       const float* __restrict__ E, const float* __restrict__ neg, float tau, float eps,
+                                                       const float* __restrict__ gout, float* __restrict__ dpool) {
+  __shared__ float red[32];
+  __shared__ f4_t part[1024];
+  extern __shared__ float coef[];  // [2N]
+  const int i = blockIdx.x, B2 = 2 * N, partner = (i + N) % B2;
+  const float w = gout[0] / B2;
+  for (int j = threadIdx.x; j < B2; j += blockDim.x) {
+    float c = 0.f;
+    if (j == partner) c = -2.f * w / tau;  // G_ip + G_pi
+    else if (j != i) c = w / tau * (E[(long long)i * B2 + j] / (neg[i] + eps) + E[(long long)j * B2 + i] / (neg[j] + eps));
+    coef[j] = c;
+  }
+  __syncthreads();
+  const int dv = D >> 2, G = 1024 / dv, g = threadIdx.x / dv, c = threadIdx.x - g * dv;
+  f4_t s = {0.f, 0.f, 0.f, 0.f};
+  if (g < G) {
+    const float* base = z + c * 4;
+    int j = g;
+    for (; j + 3 * G < B2; j += 4 * G) {
+      const f4_t a0 = *reinterpret_cast<const f4_t*>(base + (long long)j * D), a1 = *reinterpret_cast<const f4_t*>(base + (long long)(j + G) * D);
+      const f4_t a2 = *reinterpret_cast<const f4_t*>(base + (long long)(j + 2 * G) * D), a3 = *reinterpret_cast<const f4_t*>(base + (long long)(j + 3 * G) * D);
+      s += (a0 * coef[j] + a1 * coef[j + G]) + (a2 * coef[j + 2 * G] + a3 * coef[j + 3 * G]);
+    }
+    for (; j < B2; j += G) s += *reinterpret_cast<const f4_t*>(base + (long long)j * D) * coef[j];
+    part[threadIdx.x] = s;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  f4_t zi = {0.f, 0.f, 0.f, 0.f};
+  if (g == 0) {
+    for (int k = 1; k < G; ++k) s += part[k * dv + c];
+    zi = *reinterpret_cast<const f4_t*>(z + (long long)i * D + c * 4);
+    dot = (s[0] * zi[0] + s[1] * zi[1]) + (s[2] * zi[2] + s[3] * zi[3]);
+  }
+  dot = block_sum(dot, red);
+  if (g == 0) *reinterpret_cast<f4_t*>(dpool + (long long)i * D + c * 4) = (s - zi * dot) * inv_norm[i];
+}
 extern "C" int csmae_ntxent_fwd(int N, int Te, int keep, int D, const float* latent, float tau, float eps, float* z, float* inv_norm,
                                 float* E, float* neg, float* rowloss, void* stream) {
   CSMAE_REQUIRE(N > 0 && keep > 0 && keep < Te && D > 0 && D * 4 <= 64 * 1024, "csmae_ntxent_fwd: bad geometry N=%d Te=%d keep=%d D=%d", N, Te, keep, D);
@@ -483,7 +526,8 @@ extern "C" int csmae_ntxent_fwd(int N, int Te, int keep, int D, const float* lat
 extern "C" int csmae_ntxent_bwd(int N, int D, const float* z, const float* inv_norm, const float* E, const float* neg, float tau, float eps,
                                 const float* gout, float* dpool, void* stream) {
   CSMAE_REQUIRE(N > 0 && D > 0 && 2 * N * 4 <= 64 * 1024, "csmae_ntxent_bwd: bad geometry");
-  hipLaunchKernelGGL(ntx_bwd_kernel, dim3(2 * N), dim3(D >= 1024 ? 1024 : ((D + 63) / 64) * 64), 2 * N * sizeof(float), (hipStream_t)stream, N, D, z, inv_norm, E, neg, tau, eps, gout, dpool);
+  if (D % 4 == 0 && D <= 4096) hipLaunchKernelGGL(ntx_bwd4_kernel, dim3(2 * N), dim3(1024), 2 * N * sizeof(float), (hipStream_t)stream, N, D, z, inv_norm, E, neg, tau, eps, gout, dpool);
+  else hipLaunchKernelGGL(ntx_bwd_kernel, dim3(2 * N), dim3(D >= 1024 ? 1024 : ((D + 63) / 64) * 64), 2 * N * sizeof(float), (hipStream_t)stream, N, D, z, inv_norm, E, neg, tau, eps, gout, dpool);
   return csmae_check_launch("csmae_ntxent_bwd");
 }
 // dlat[n, t>=1, :] += dpool[n, :] * inv_keep ; then emit the low-precision copy that the encoder backward GEMMs consume
