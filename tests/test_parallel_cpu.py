@@ -59,6 +59,14 @@ def _worker(rank, world, port, q):
         want = torch.stack(others).mean(0)
         assert torch.allclose(flat, want, atol=1e-6), float((flat - want).abs().max())
         assert torch.equal(others[rank], mine)
+        # per-bucket timing (bench.py's data_parallel diagnosis) is a GPU-side measurement: on CPU tensors it is inert and the exchange unchanged
+        flat3 = mine.clone()
+        s3 = GradSync(flat3)
+        s3.timing = True
+        for _, lo, hi in ranges:
+            s3.reduce_range(lo, hi)
+        s3.finish()
+        assert s3.bucket_times() == [] and torch.allclose(flat3, want, atol=1e-6) and len(s3.issued) == len(ranges)
         # bf16 payload variant stays within bf16 rounding of the exact mean
         flat2 = mine.clone()
         s2 = GradSync(flat2, comm_dtype=torch.bfloat16)
