@@ -160,6 +160,15 @@ def test_paired_two_explicit_views_vs_reference_and_oracle(tag, kw):
         if q.grad is not None:
             ref = osd[n].grad
             np.testing.assert_allclose(q.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-4 * ref.abs().max().item() + 1e-9, err_msg=n)
+    # the bf16 MFMA engine on the same views: bf16 predictions, loss within the bf16 band of the reference's
+    m.zero_grad()
+    m.compute_dtype = torch.bfloat16
+    m._test_draws = dict(noise=noise, box=None)
+    lb, pb, mb = m(i1.cuda(), i2.cuda(), mask_ratio=0.75, **kw)
+    assert pb.dtype == torch.bfloat16 and rel(lb, p[f"{tag}_loss"]) < 2e-2 and np.array_equal(mb.cpu().numpy(), p[f"{tag}_mask"])
+    lb.backward()
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
+    m.compute_dtype = torch.float32
     # without injected draws: the seeding rule of the reference (both views masked alike under mask_seed / consistent_mask)
     m.zero_grad()
     out2 = m(i1.cuda(), i2.cuda(), mask_ratio=0.75, mask_seed=3)

@@ -641,6 +641,33 @@ def test_bnrelu_token_axis(ops, dtype, geom):
 
 
 # ------------------------------------------------------------------------------------------------ token plumbing
+def test_cu_masked_stream_runs_kernels_and_rejects_an_empty_mask(ops):
+    """csmae_stream_create_cu_mask / csmae_stream_destroy (the CU-partition experiment's tool): a stream confined to a
+    few CUs of every XCD runs the library's kernels with the same results; an empty mask is an error, not a queue that never finishes."""
+    import ctypes
+    import csmae_hip
+    st = ops.cu_masked_stream(0, 64)                      # 8 CUs of every XCD
+    assert ops.cu_masked_stream(0, 64) is st              # cached per range
+    src = rnd(100003, seed=5).cuda()
+    a, b = torch.empty(100003, device="cuda", dtype=torch.bfloat16), torch.empty(100003, device="cuda", dtype=torch.bfloat16)
+    ops.cast_bf16(src, a)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ops.cast_bf16(src, b)
+    torch.cuda.current_stream().wait_stream(st)
+    assert torch.equal(a, b)
+    lib = csmae_hip.load()
+    h = ctypes.c_void_p()
+    zero = (ctypes.c_uint32 * 8)(*([0] * 8))
+    rc = lib.csmae_stream_create_cu_mask(8, ctypes.cast(zero, ctypes.c_void_p), ctypes.cast(ctypes.byref(h), ctypes.c_void_p))
+    assert rc != 0 and b"empty mask" in lib.csmae_last_error()
+    one = (ctypes.c_uint32 * 8)(*([0xFFFFFFFF] * 8))
+    assert lib.csmae_stream_create_cu_mask(8, ctypes.cast(one, ctypes.c_void_p), ctypes.cast(ctypes.byref(h), ctypes.c_void_p)) == 0 and h.value
+    assert lib.csmae_stream_destroy(h) == 0
+    with pytest.raises(ValueError):
+        ops.cu_masked_stream(10, 10)
+
+
 @pytest.mark.parametrize("D", [7, 64, 768])
 def test_random_masking_helper_gathers_through_hip(ops, D):
     """MAE_ViT_Shared.py:57-84 as a stand-alone helper: kept rows == torch.gather over the kernel's own ids (the noise is drawn inside)."""
