@@ -955,11 +955,11 @@ class Engine:
                 # weight-gradient launches wait for events recorded on the auxiliary stream.
                 aux, ast = self.aux, self.aux.cuda_stream
                 aux.wait_event(head_start)                   # gout, and everything the forward pass left on the main stream
-                if zeroed is not None:
-                    aux.wait_event(zeroed)                   # (BatchNorm's parameter gradients go straight into the flat buffer)
                 ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
                                   da_lp=ws.dv, st=ast)
                 ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=ast)
+                if zeroed is not None:   # BatchNorm's parameter gradients go straight into the flat buffer: the chain's first writer into it waits
+                    aux.wait_event(zeroed)   # for the clear — not its head (the clear is a 117-us fill that starts with the backward pass)
                 ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=ast)
                 ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=ast)
                 self.main.wait_stream(aux)
