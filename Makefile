@@ -11,7 +11,7 @@ all: $(LIB)
 # the content hash of csrc/ is baked into the library (csmae_source_hash()): a profile or a bench line can then say which sources the
 # kernels it measured were built from.  build/obj/src_hash.txt is rewritten only when the hash moves, so api.o rebuilds exactly then.
 SRC_HASH := $(shell python3 tools/csrc_hash.py)
-build/obj/src_hash.txt: $(SRC) $(PKG)/csrc/common.h
+build/obj/src_hash.txt: $(SRC) $(PKG)/csrc/common.h $(PKG)/csrc/gemm_common.h
 	@mkdir -p build/obj
 	@echo '$(SRC_HASH)' | cmp -s - $@ || echo '$(SRC_HASH)' > $@
 
@@ -19,7 +19,7 @@ build/obj/api.o: $(PKG)/csrc/api.hip $(PKG)/csrc/common.h build/obj/src_hash.txt
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -DCSMAE_SRC_HASH='"$(SRC_HASH)"' -c $< -o $@
 
-build/obj/%.o: $(PKG)/csrc/%.hip $(PKG)/csrc/common.h
+build/obj/%.o: $(PKG)/csrc/%.hip $(PKG)/csrc/common.h $(PKG)/csrc/gemm_common.h
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 import torch  # noqa: F401  -- must come first: libcsmae_hip.so has to bind to the HIP runtime PyTorch already loaded (one runtime per process)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
 LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4, "none": 5}
 # the ssim family: kind -> (per-patch kind, pyramid levels, weight of the ssim term)  MAE_ViT_Shared.py:165-267
@@ -24,6 +24,9 @@ LIB_PATH = os.environ.get("CSMAE_LIB_PATH") or os.path.join(_HERE, "libcsmae_hip
 I, L, P, F = c_int, c_longlong, c_void_p, c_float
 _SIGNATURES = {
     "csmae_gemm": [I, I, I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, I, P],
+    "csmae_gemm_ks": [I, L, L, L, P, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P],
+    "csmae_weights_kslab": [I, P, I, P, P, P],
+    "csmae_gemm_k2_mode": [I, I],
     "csmae_gemm_dw": [I, L, L, L, P, L, P, L, P, P, P, L, P],
     "csmae_gemm_dw_group": [I, I, L, P, P, P, P, P, P, P, P, I, P, L, P],
     "csmae_fp8_amax": [I, L, I, P, L, P, P],

@@ -264,6 +264,7 @@ class Engine:
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
+        self.use_ks = not os.environ.get("CSMAE_NO_KSLAB")   # A/B aid: forward products through csmae_gemm (one 256 x 256 workgroup per CU) instead of csmae_gemm_ks
         self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
         # 128 workgroups = 4 / 8 whole K slices of its 32- and 16-tile launches (160 -> 128: -0.15 .. -0.3 ms per step; 64: +1.4 ms)
@@ -308,6 +309,25 @@ class Engine:
             P = self.cfg["P"]
             self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
             self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
+        self._refresh_ks()
+
+    def _refresh_ks(self):
+        """K-slab mirrors of the blocks' Linear weights (csmae.h csmae_gemm_ks: the forward products' B operand on the two-workgroups-per-CU
+        kernel), re-made from the bf16 mirror whenever that one has moved: one launch over all 4 x (Ne + Nd) weights, ~0.35 GB of HBM traffic
+        for ViT-B.  Lives on the FlatParams like the bf16 mirror (every engine of a model shares it)."""
+        f = self.flat
+        if self.T != BF16 or self.fp8 or not self.use_ks:
+            return
+        if getattr(f, "w_ks", None) is None:
+            names = [n for n in self._fp8_names() if f.slots[n][2][1] % 64 == 0]
+            f.w_ks = torch.zeros(f.total, device=self.device, dtype=torch.bfloat16)
+            f.ks_names = set(names)
+            f.ks_desc = torch.tensor([[f.slots[n][0], f.slots[n][2][0], f.slots[n][2][1]] for n in names], dtype=torch.long, device=self.device).reshape(-1, 3)
+            f.ks_stamp = None
+        stamp = (f.lp_stamp, f.raw_writes)
+        if stamp != f.ks_stamp and f.ks_desc.shape[0]:
+            ops.weights_kslab(f.ks_desc, f.w_lp, f.w_ks)
+            f.ks_stamp = stamp
 
     def _w_pe(self):
         if self.T == BF16 and self.Pp != self.cfg["P"]:
@@ -378,6 +398,10 @@ class Engine:
         copy (ws.q_b) itself; `site`: this product's A operand belongs to that pre-allocated site; `a8`: ... and its producer has
         already left it there as fp8 bytes (the `emit` of _emit())."""
         if not self.fp8:
+            f = self.flat
+            if not trans_b and self.T == BF16 and self.use_ks and name in f.ks_names:   # forward product: the weight's K-slab mirror (two workgroups per CU)
+                o, cnt, _ = f.slots[name]
+                return ops.gemm_ks(a, f.w_ks[o:o + cnt], self.W(name), out, bias=bias, epilogue=epilogue, aux=aux, resid=resid, st=st)
             return ops.gemm(a, self.W(name), out, trans_b=trans_b, bias=bias, epilogue=epilogue, aux=aux, resid=resid, st=st)
         f, ws = self.flat, self.ws
         M, K = a.shape

@@ -125,6 +125,30 @@ def gemm(a, b, out, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NON
     return out
 
 
+def gemm_ks(a, bk, b_plain, out, *, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None):
+    """out[M,N] = a[M,K] W^T (+ epilogue) with W [N,K] given twice: `bk` its K-slab mirror (flat bf16, Wk[K/32][N][32], weights_kslab) for the
+    two-workgroups-per-CU kernel, `b_plain` in torch's layout for the shapes that kernel does not take."""
+    M, K = a.shape
+    N = b_plain.shape[0]
+    assert b_plain.shape[1] == K and out.shape == (M, N) and a.stride(1) == 1 and out.stride(1) == 1 and b_plain.stride(1) == 1
+    assert resid is None or resid.dtype == out.dtype
+    if aux is not None and aux.dtype == torch.uint8:
+        epilogue = {EPI_GELU: 6, EPI_DGELU: 7}[epilogue]
+    if _timer is not None:
+        _timer.begin()
+    check(load().csmae_gemm_ks(dt(a), M, N, K, _p(a), a.stride(0), _p(bk), N, _p(b_plain), b_plain.stride(0), _p(out), out.stride(0), dt(out), _p(bias),
+                               epilogue, _p(aux), aux.stride(0) if aux is not None else 0, _p(resid), resid.stride(0) if resid is not None else 0,
+                               st if st is not None else stream()), "csmae_gemm_ks")
+    if _timer is not None:
+        _timer.end(("gemm_bf16" if a.dtype == torch.bfloat16 else "gemm_f32") + "_NT", 2.0 * M * N * K)
+    return out
+
+
+def weights_kslab(desc, src, dst, max_blocks=64, st=None):
+    """K-slab mirrors (csmae.h csmae_gemm_ks) of the weights in desc (int64 [count, 3] on the device: flat offset, out, in) from the bf16 mirror."""
+    check(load().csmae_weights_kslab(desc.shape[0], _p(desc), max_blocks, _p(src), _p(dst), st if st is not None else stream()), "csmae_weights_kslab")
+
+
 def gemm_dw(dy, x, dw, workspace, db=None, st=None):
     """dw[out,in] (fp32, contiguous) += dy[tokens,out]^T x[tokens,in] via split-K slabs in `workspace` (fp32); db[out] += colsum(dy)."""
     K, M = dy.shape

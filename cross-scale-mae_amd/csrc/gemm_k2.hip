@@ -1,0 +1,317 @@
+// Two-workgroups-per-CU bf16 GEMM (round 5) and the K-slab weight mirror it reads.  See gemm_common.h for the shared epilogues.
+#include "gemm_common.h"
+#ifdef GEMM_TIMING
+extern "C" int csmae_debug_k2_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_ts), sizeof(g_gemm_ts)); }
+#endif
+
+// ------------------------------------------------------------------------------------ bf16 MFMA, two workgroups per CU (round 5)
+// The 256 x 256 workgroup above owns its CU (160 KiB of LDS, every VGPR): while it waits for its first operands (prologue, ~4 k clocks) and
+// while it stores its C tile (5 k .. 15 k clocks) the CU's matrix pipes idle — 28-36 % of a tile's life at K = 512 .. 768, which is most of
+// the step.  This kernel halves the workgroup instead of tuning it: 128 x 256 tile, FOUR waves (one per SIMD, each the same
+// 128 x 64 wave tile and the same software-pipelined K step as k64_tile), 80 KiB of LDS, <= 256 VGPRs — so TWO workgroups share a CU and
+// one's prologue / epilogue runs under the other's main loop.  What makes the ring fit in 80 KiB:
+//   * the four waves sit side by side along N (1 x 4), so a wave's 64 B columns are read by nobody else: every wave stages ITS OWN B rows
+//     into a wave-private ring (no barrier, no cross-wave hazard: the wave's own counted vmcnt orders DMA against its reads);
+//   * B is fetched in 32-wide K HALVES (a half is consumed in half a K step), which needs rows of 64 B that are still whole cache lines
+//     for the DMA — the "K-slab" weight mirror Wk[K/32][N][32] (csmae_weights_kslab): 16 consecutive rows of a slab are 1 KiB contiguous;
+//     (K-strided B, i.e. dX = dY W with W [K][N]: 8 k-rows x 128 B per piece, whole lines by nature);
+//   * A (activations, shared by the four waves) stays a [128 rows][64 k] image of whole 128-B lines, two slots, one barrier per K step.
+// LDS: A 2 x 16 KiB | per wave 3 x 4 KiB of B halves (B_j^0, B_j^1, B_{j+1}^0 rotate through three slots) = 80 KiB; every unit is in flight
+// for exactly one K step.  The epilogue strip of a wave is its own B ring (8.5 of 12 KiB): no barrier between loop and epilogue either.
+// Cost: 96 instead of 64 KiB staged per 256 x 256 x 64 of MFMA work (the A image serves half as many columns).
+// main-loop ablations, compile-time only (tools/k2_variants.sh builds variant libraries; never in the product build):
+// -DK2_ABL=1 no fragment reads | 2 no DMA pieces | 4 no MFMAs | 8 no barrier | 16 every DMA piece re-fetches K step 0 (cache-resident operands)
+#ifndef K2_ABL
+#define K2_ABL 0
+#endif
+template <bool TB>
+__device__ __forceinline__ void k2_tile(const GemmArgs& p, const int tm, const int tn) {
+  constexpr int WM = 128, WN = 64, NW = 4, FM = 8, FN = 4;
+  constexpr int ASLOT = 128 * 64 * 2, BSLOT = 64 * 32 * 2, BWAVE = 3 * BSLOT, BBASE = 2 * ASLOT;   // 16 KiB | 4 KiB | 12 KiB | 32 KiB
+  __shared__ __attribute__((aligned(16))) char smem[BBASE + NW * BWAVE];                            // 80 KiB
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = lane & 15, g = lane >> 4;
+  const int m0 = tm * 128, n0 = tn * 256, wn = w * WN;
+  GTS(0);
+  const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  // ---- DMA descriptors
+  // A image [128 rows][64 k]: piece = 8 rows x 128 B, lane -> row (lane >> 3), physical 16-B chunk (lane & 7) holds logical chunk ^ (row & 7);
+  //   wave w stages rows 32 w .. 32 w + 31 (pieces 4 w .. 4 w + 3)
+  // B half [64 rows][32 k] (K-contiguous, K-slab mirror): piece = 16 rows x 64 B = 1 KiB contiguous in the slab, lane -> row (lane >> 2),
+  //   physical chunk (lane & 3) holds logical chunk ^ ((row >> 1) & 3)
+  // B half [32 k][64 cols] (K-strided): piece = 8 k-rows x 128 B, 32-B granule swizzle of the transposing read (see read_b)
+  const int l3 = lane >> 3;
+  const unsigned avo = (unsigned)(((long long)(m0 + w * 32 + l3) * p.lda + ((lane & 7) ^ l3) * 8) * 2);
+  const unsigned aqs = (unsigned)(8 * p.lda * 2);
+  unsigned bvo[2], bqs, bhs;   // lane offset (even / odd piece: they differ in the K-strided image's swizzle only) | advance per piece | advance per K half
+  if (!TB) {
+    const int r = lane >> 2, c = (lane & 3) ^ ((r >> 1) & 3);
+    bvo[0] = bvo[1] = (unsigned)(((long long)(n0 + wn + r) * 32 + c * 8) * 2);
+    bqs = 16u * 64u;
+    bhs = (unsigned)(p.ldb * 64);        // ldb = rows per K slab (the weight's out-features)
+  } else {
+    // k-row = 8 q + (lane >> 3), 16-B chunk (lane & 7) of its 128 B; the 32-B granule (chunk >> 1) holds logical granule ^ key(k-row),
+    // key(r) = ((r >> 1) & 1) | (((r >> 3) & 1) << 1): the 8 k-rows one LDS cycle of a transposing read touches ({0..3, 8..11} + 16 s + 4 hi)
+    // fall on 8 distinct 32-B slots of the 256-B bank row
+    const int kr = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int qo = 0; qo < 2; ++qo) {
+      const int key = ((kr >> 1) & 1) | (qo << 1);
+      bvo[qo] = (unsigned)(((long long)kr * p.ldb + n0 + wn + ((((ch >> 1) ^ key) << 1) | (ch & 1)) * 8) * 2);
+    }
+    bqs = (unsigned)(8 * p.ldb * 2);
+    bhs = (unsigned)(32 * p.ldb * 2);
+  }
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+  const unsigned ldsA = lds0 + (unsigned)(w * 4) * 1024u, ldsB = lds0 + (unsigned)(BBASE + w * BWAVE);
+  auto dma_a = [&](int slot, int j, int q) {   // piece q of this wave's share of A_j
+    if (K2_ABL & 2) return;
+    if (K2_ABL & 16) j = 0;
+    lds_dma16u(rsA, avo + ((unsigned)j * 128u + (unsigned)q * aqs), ldsA + (unsigned)(slot * ASLOT + q * 1024));
+  };
+  auto dma_b = [&](int slot, int u, int q) {   // piece q of this wave's B half u (= 2 j + h)
+    if (K2_ABL & 2) return;
+    if (K2_ABL & 16) u &= 1;
+    lds_dma16u(rsB, bvo[q & 1] + ((unsigned)u * bhs + (unsigned)q * bqs), ldsB + (unsigned)(slot * BSLOT + q * 1024));
+  };
+  f4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < FN; ++jj) acc[i][jj] = f4_t{0.f, 0.f, 0.f, 0.f};
+  // fragment offsets: A as in k64_tile (K half h: ^ (h << 6), fragment i: + i * 2048); B half (K-contiguous): row (16 jn + t) * 64 B,
+  // chunk g ^ ((t >> 1) & 3) — the four lane groups of a ds_read_b128 fall on 16 distinct 16-B slots of the 256-B bank row
+  const int ra0 = t * 128 + ((g ^ (t & 7)) << 4);
+  // B half (K-strided, [32 k][64 cols], 128-B rows): lane (t, g) addresses k-row 8 g + (t >> 2) (+ 4 for the fragment's high half), the 8 bytes
+  // (t & 3) of granule jn ^ key — bits 5..6 of the offset hold only that XOR, so fragment jn is `rb0 ^ (jn << 5)`
+  const int rb0 = !TB ? t * 64 + ((g ^ ((t >> 1) & 3)) << 4)
+                      : (8 * g + (t >> 2)) * 128 + ((((t >> 3) & 1) | ((g & 1) << 1)) << 5) + (t & 3) * 8;
+  constexpr int BOPS = TB ? 2 * FN : FN;
+  constexpr int W0_0 = (FM - 2) + BOPS, W0_I = (FM - 1) + BOPS, W1 = FM - 2;
+  static_assert(W0_I <= 15, "lgkmcnt is a 4-bit counter");
+  auto read_a = [&](int slot, int h, auto ic, s8_t& fa) {
+    constexpr int i = decltype(ic)::value;
+    if (K2_ABL & 1) return;
+    const unsigned addr = lds0 + (unsigned)(slot * ASLOT) + (unsigned)(ra0 ^ (h << 6));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(fa) : "v"(addr), "n"(i * 2048));
+  };
+  auto read_b = [&](int slot, s8_t (&fb)[FN]) {
+    if (K2_ABL & 1) return;
+    const unsigned addr = ldsB + (unsigned)(slot * BSLOT) + (unsigned)rb0;
+    if (!TB) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(addr));
+      asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[1]) : "v"(addr));
+      asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fb[2]) : "v"(addr));
+      asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(fb[3]) : "v"(addr));
+    } else {
+#pragma unroll
+      for (int jn = 0; jn < FN; ++jn) {
+        const unsigned a2 = ldsB + (unsigned)(slot * BSLOT) + (unsigned)(rb0 ^ (jn << 5));
+        s4_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a2));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi) : "v"(a2));
+        fb[jn] = join_s4(lo, hi);
+      }
+    }
+  };
+  auto wait_a = [&](auto n, s8_t& f0) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f0) : "n"(decltype(n)::value)); };
+  auto wait_ab = [&](auto n, s8_t& f0, s8_t& f1, s8_t (&fb)[FN]) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f0), "+v"(f1), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) : "n"(decltype(n)::value));
+  };
+  auto mma_row = [&](int i, const s8_t& fa, const s8_t (&fb)[FN]) {
+    if (K2_ABL & 4) return;
+#pragma unroll
+    for (int jj = 0; jj < FN; ++jj)
+      acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fb[jj]), __builtin_bit_cast(bf8_t, fa), acc[i][jj], 0, 0, 0);
+  };
+  // ---- prologue: A_0, B_0^0, B_0^1 (needed at once), A_1, B_1^0 (needed at step 0's barrier).  B half u lives in slot u % 3, A_j in slot j & 1.
+  const int nsteps = p.ktiles;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_a(0, 0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_b(0, 0, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_b(1, 1, q);
+  if (nsteps >= 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_a(1, 1, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_b(2, 2, q);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  GTS(1);
+  s8_t fa[FM], fb0[FN], fb1[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) fa[i] = s8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  read_a(0, 0, std::integral_constant<int, 0>{}, fa[0]); read_a(0, 0, std::integral_constant<int, 1>{}, fa[1]);
+  read_b(0, fb0);
+  static_for<FM - 2>([&](auto ic) { constexpr int i = decltype(ic)::value + 2; read_a(0, 0, std::integral_constant<int, i>{}, fa[i]); });
+  auto nx3 = [](int s, int k) { s += k; return s >= 3 ? s - 3 : s; };
+  // One K step (64 wide) = 16 rows of 4 MFMAs, straight-line code.  Slots on entry: A_j in `sa`, B_j^0 (already in fb0) in `sb`, B_j^1 in sb + 1,
+  // B_{j+1}^0 in sb + 2 (mod 3).  DMA of the step, one piece per row: B_{j+1}^1 into B_j^0's slot (rows 1, 3, 5, 7: fb0 was complete at row 0),
+  // B_{j+2}^0 into B_j^1's slot (rows 8, 9, 14, 15: fb1 was complete at row 8), A_{j+2} into A_j's slot behind the barrier (rows 10 .. 13).
+  // vmcnt (in issue order per wave and step: 4 b1 | 2 b0 | 4 a | 2 b0): at the step's head B_j^1 — issued in the previous step's first half —
+  // has the 8 pieces of that step's second half behind it; at the barrier A_{j+1} and B_{j+1}^0 have this step's 4 + 2 behind them.
+  // MODE 0: steady state   2: second-to-last step (nothing left to fetch but B_{j+1}^1)   3: last step (no fetch, no prefetch, no barrier)
+  auto step = [&](int j, int sa, int sb, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool more = MODE < 3;
+    const int sb1 = nx3(sb, 1), sb2 = nx3(sb, 2);
+    if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    read_b(sb1, fb1);
+    static_for<FM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (i == 0) wait_ab(std::integral_constant<int, W0_0>{}, fa[0], fa[1], fb0);
+      else if (i >= 2) wait_a(std::integral_constant<int, W0_I>{}, fa[i]);
+      mma_row(i, fa[i], fb0);
+      read_a(sa, 1, ic, fa[i]);
+      if (more && (i & 1)) dma_b(sb, 2 * j + 3, i >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    wait_ab(std::integral_constant<int, W1>{}, fa[0], fa[1], fb1);
+    mma_row(0, fa[0], fb1);
+    if (MODE == 0) dma_b(sb1, 2 * j + 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_row(1, fa[1], fb1);
+    if (MODE == 0) dma_b(sb1, 2 * j + 4, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (MODE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of the step is in registers (the last step too: rows 2 .. 7 below read fa[2 .. 7])
+    if (more && !(K2_ABL & 8)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      read_a(sa ^ 1, 0, std::integral_constant<int, 0>{}, fa[0]); read_a(sa ^ 1, 0, std::integral_constant<int, 1>{}, fa[1]); read_b(sb2, fb0);
+    }
+    static_for<FM - 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value + 2;
+      mma_row(i, fa[i], fb1);
+      if (more) read_a(sa ^ 1, 0, std::integral_constant<int, i>{}, fa[i]);
+      if (MODE == 0) { if (i < 6) dma_a(sa, j + 2, i - 2); else dma_b(sb1, 2 * j + 4, i - 4); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  int j = 0, sa = 0, sb = 0;
+  for (; j < nsteps - 2; ++j, sa ^= 1, sb = nx3(sb, 2)) step(j, sa, sb, std::integral_constant<int, 0>{});
+  if (nsteps >= 2) { step(j, sa, sb, std::integral_constant<int, 2>{}); ++j; sa ^= 1; sb = nx3(sb, 2); }
+  step(j, sa, sb, std::integral_constant<int, 3>{});
+  GTS(2);
+  if ((p.force_cfg & 16) && acc[0][0][0] != 123456.0f) return;  // tuning aid: main loop only
+  // ---- epilogue: the k64 kernel's row-segment epilogues; the strip is this wave's own B ring (its last reads were waited for in the last step)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
+  static_assert(EROWS * ESTR * 4 <= BWAVE, "epilogue strip must fit the wave's B ring");
+  void* Cptr = p.C;
+  float* ew = reinterpret_cast<float*>(smem + BBASE + w * BWAVE);
+#define EPI_CALL(TC_, E_) epilogue_rows<TC_, E_, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, Cptr, acc, ew, m0, n0 + wn, lane, t, g)
+#define EPI_CALL8(E_) epilogue_rows_bf16x8<E_, FM, FN, WM, EROWS, ESTR>(p, Cptr, acc, ew, m0, n0 + wn, lane, t, g)
+#define EPI_CALL8B(E_) epilogue_rows_bf16x8b<E_, FM, FN, WM, EROWS, ESTR>(p, acc, ew, m0, n0 + wn, lane, t, g)
+  const bool wide = (p.ldc % 8 == 0) && (p.epi == EPI_NONE || (p.epi == EPI_RESID ? (p.ldr % 8 == 0 && (uintptr_t)p.resid % 16 == 0)
+                                                                                   : (p.ldaux % 8 == 0 && (uintptr_t)p.aux % 16 == 0)));
+  if (p.c_dtype == CSMAE_BF16) {
+    if (wide && p.epi == EPI_NONE) epilogue_rows_bf16_plain<FM, FN, WM>(p, Cptr, acc, reinterpret_cast<char*>(ew), m0, n0 + wn, lane, t, g);
+    else if (wide && (p.a_fmt & 256)) { if (p.epi == EPI_GELU) EPI_CALL8B(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8B(EPI_DGELU); else EPI_CALL8B(EPI_RESID); }
+    else if (wide) { if (p.epi == EPI_GELU) EPI_CALL8(EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL8(EPI_DGELU); else EPI_CALL8(EPI_RESID); }
+    else if (p.epi == EPI_RESID) EPI_CALL(bf16_t, EPI_RESID);
+    else if (p.epi == EPI_GELU) EPI_CALL(bf16_t, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(bf16_t, EPI_DGELU);
+    else EPI_CALL(bf16_t, EPI_NONE);
+  } else {
+    if (p.epi == EPI_GELU) EPI_CALL(float, EPI_GELU); else if (p.epi == EPI_DGELU) EPI_CALL(float, EPI_DGELU);
+    else if (p.epi == EPI_RESID) EPI_CALL(float, EPI_RESID); else EPI_CALL(float, EPI_NONE);
+  }
+#undef EPI_CALL
+#undef EPI_CALL8
+#undef EPI_CALL8B
+  GTS(3);
+}
+template <bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_k2_kernel(GemmArgs p) {
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  // Phase offset between the two workgroups of a CU.  A launch's first 512 workgroups start together and every tile takes the same time, so the
+  // pair on a CU would stay IN phase for the whole launch — both in their loops, then both in their epilogues with the matrix pipes idle: the
+  // overlap this kernel exists for would never happen (measured: same tile time as alone).  The second workgroup of every CU (ids 256 .. 511:
+  // the dispatcher deals the first 256 one per CU) therefore sleeps about half a tile time once; equal tile times keep the offset afterwards.
+  if (blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = (int)p.split_stride; i > 0; --i) __builtin_amdgcn_s_sleep(127);   // 127 x 64 clocks per iteration
+  }
+  k2_tile<TB>(p, tm, tn);
+}
+// Clocks the second workgroup of a CU sleeps at the start of a launch (CSMAE_K2_STAGGER="a,b": a + b * K steps; default none).  Measured
+// (gpurun_out/r05d): with half a tile time of offset the delayed workgroup's loop runs at 2 100 instead of 2 480 clocks per K step, the launch
+// as a whole no faster — a workgroup alone on the matrix pipes is bound by its own DMA issue (12 pieces per wave and step), not by the pipe.
+static long long k2_stagger_sleeps(int nsteps, int epi) {
+  static int a = -1, b = -1;
+  if (a < 0) { const char* e = getenv("CSMAE_K2_STAGGER"); if (!e || sscanf(e, "%d,%d", &a, &b) != 2) { a = 0; b = 0; } }
+  if (a == 0 && b == 0) return 0;
+  const long long clk = a + (long long)b * nsteps + ((epi == EPI_GELU || epi == EPI_DGELU) ? 4000 : 0);
+  return clk / (127 * 64);
+}
+int gemm_k2_launch_nn(const GemmArgs& p0, hipStream_t st) {
+  GemmArgs p = p0;
+  p.split_stride = k2_stagger_sleeps(p.ktiles, p.epi);
+  CSMAE_LAUNCH((gemm_bf16_k2_kernel<true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  return 0;
+}
+
+// ---- y = x W^T with W given as its K-slab mirror Wk[K/32][N][32] (csmae_weights_kslab): the forward products on the two-workgroups-per-CU
+// kernel (k2_tile).  `B_plain` ([N][K], ldb_plain) is the same weight in torch's layout: shapes the kernel does not take (K % 64, small M / N,
+// fp32 parity mode) go through csmae_gemm with it, so the caller never branches.
+extern "C" int csmae_gemm_ks(int dtype, long long M, long long N, long long K, const void* A, long long lda, const void* Bk, long long slab_rows,
+                             const void* B_plain, long long ldb_plain, void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
+                             void* aux, long long ldaux, const void* resid, long long ldr, void* stream) {
+  const int epi_kind = epilogue == 6 ? EPI_GELU : (epilogue == 7 ? EPI_DGELU : epilogue);
+  const bool ok = dtype == CSMAE_BF16 && Bk && gemm_k2_nt_wanted(epi_kind, K) && (gemm_force_cfg() < 0 || (gemm_force_cfg() & 7) == 6) && K % 64 == 0 && M >= 128 && N >= 256 && N % 4 == 0 && ldc % 4 == 0 &&
+                  lda % 8 == 0 && slab_rows >= N && (M + 128) * lda * 2 < 0xFFFFFFF0ll && (K / 32) * slab_rows * 64 < 0xFFFFFFF0ll &&
+                  (((uintptr_t)A | (uintptr_t)Bk | (uintptr_t)C) & 15) == 0;
+  if (!ok) {
+    CSMAE_REQUIRE(B_plain != nullptr, "csmae_gemm_ks: shape not taken by the K-slab kernel and no plain weight given (M=%lld N=%lld K=%lld)", M, N, K);
+    return gemm_core(dtype, 0, 0, M, N, K, A, lda, B_plain, ldb_plain, C, ldc, c_dtype, bias, epilogue, aux, ldaux, resid, ldr, 1, stream);
+  }
+  const int q8 = (epilogue == 6 || epilogue == 7);
+  if (q8) epilogue = epilogue == 6 ? EPI_GELU : EPI_DGELU;
+  CSMAE_REQUIRE(!q8 || c_dtype == CSMAE_BF16, "csmae_gemm_ks: the 8-bit gelu' epilogues write bf16");
+  CSMAE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_DGELU, "csmae_gemm_ks: bad epilogue %d", epilogue);
+  CSMAE_REQUIRE(!(epilogue == EPI_GELU || epilogue == EPI_DGELU) || (aux && ldaux % 4 == 0), "csmae_gemm_ks: gelu epilogues need aux");
+  CSMAE_REQUIRE(epilogue != EPI_RESID || (resid && ldr % 4 == 0), "csmae_gemm_ks: residual epilogue needs resid");
+  GemmArgs p;
+  p.force_cfg = 0; p.split_stride = 0; p.colsum = nullptr; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = q8; p.q_out = nullptr;
+  p.A = A; p.B = Bk; p.C = C; p.bias = (epilogue >= EPI_DGELU) ? nullptr : bias; p.aux = aux; p.resid = resid;
+  p.lda = lda; p.ldb = slab_rows; p.ldc = ldc; p.ldaux = ldaux; p.ldr = ldr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.c_dtype = c_dtype; p.epi = epilogue; p.splitk = 1;
+  p.a_bytes = (unsigned)(M * lda * 2); p.b_bytes = (unsigned)((K / 32) * slab_rows * 64);
+  p.ktiles = (int)(K / 64); p.ktiles_per_split = p.ktiles;
+  p.tiles_m = cdiv(M, 128); p.tiles_n = cdiv(N, 256);
+  if (c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll && (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) &&
+      ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) && !getenv("CSMAE_EPI_POINTERS"))
+    p.a_fmt |= 256;
+  p.split_stride = k2_stagger_sleeps(p.ktiles, p.epi);
+  CSMAE_LAUNCH((gemm_bf16_k2_kernel<false>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, (hipStream_t)stream, p);
+  return csmae_check_launch("csmae_gemm_ks");
+}
+// K-slab mirrors of `count` weights in one launch: desc[i] = {offset (elements) of weight i in `src` AND in `dst`, out-features N, in-features K}
+// (K % 32 == 0): dst[off + (k / 32) * N * 32 + n * 32 + k % 32] = src[off + n * K + k].  A workgroup moves 32 rows x 64 k through LDS: 128-B
+// row segments in, 2 x (32 rows x 64 B = 2 KiB contiguous) out.  blockIdx.y = weight.
+__global__ __launch_bounds__(256) void weights_kslab_kernel(const long long* __restrict__ desc, const bf16_t* __restrict__ src, bf16_t* __restrict__ dst) {
+  const long long off = desc[blockIdx.y * 3 + 0];
+  const int N = (int)desc[blockIdx.y * 3 + 1], K = (int)desc[blockIdx.y * 3 + 2];
+  const int kb2 = K / 64, nblk = (N + 31) / 32;
+  __shared__ uint4 tile[32][9];   // 32 rows x 128 B (+ pad)
+  for (int b = blockIdx.x; b < nblk * kb2; b += gridDim.x) {
+    const int nb = b / kb2, k2 = b - nb * kb2;
+    const int r = threadIdx.x >> 3, c = threadIdx.x & 7, n = nb * 32 + r;
+    __syncthreads();
+    if (n < N) tile[r][c] = *reinterpret_cast<const uint4*>(src + off + (long long)n * K + k2 * 64 + c * 8);
+    __syncthreads();
+    // out: slab 2 k2 + h, rows nb * 32 .. + 31, 64 B each: thread -> (h = tid >> 7, row = (tid >> 2) & 31, 16-B chunk tid & 3)
+    const int h = threadIdx.x >> 7, ro = (threadIdx.x >> 2) & 31, co = threadIdx.x & 3, no = nb * 32 + ro;
+    if (no < N) *reinterpret_cast<uint4*>(dst + off + ((long long)(2 * k2 + h) * N + no) * 32 + co * 8) = tile[ro][h * 4 + co];
+  }
+}
+extern "C" int csmae_weights_kslab(int count, const long long* desc, int max_blocks, const void* src_bf16, void* dst_bf16, void* stream) {
+  CSMAE_REQUIRE(count > 0 && desc && src_bf16 && dst_bf16 && max_blocks > 0, "csmae_weights_kslab: bad arguments");
+  hipLaunchKernelGGL(weights_kslab_kernel, dim3((unsigned)max_blocks, (unsigned)count), dim3(256), 0, (hipStream_t)stream, desc,
+                     reinterpret_cast<const bf16_t*>(src_bf16), reinterpret_cast<bf16_t*>(dst_bf16));
+  return csmae_check_launch("csmae_weights_kslab");
+}
+

@@ -53,6 +53,22 @@ int csmae_gemm(int dtype, int transA, int transB, long long M, long long N, long
                const float* bias, int epilogue, void* aux, long long ldaux, const void* resid /* in C's dtype */, long long ldr,
                int splitk, void* stream);
 
+/* ---- the same forward product y = x W^T (+ epilogue) with the weight given as its K-SLAB mirror (ABI version 6): Wk[K/32][slab_rows][32] bf16,
+ * Wk[(k / 32) * slab_rows * 32 + n * 32 + k % 32] = W[n][k] — written by csmae_weights_kslab from the bf16 weight mirror after every optimizer
+ * step.  Rows of a slab are 64 B, so 16 consecutive rows of one 32-wide K half are 1 KiB contiguous: the 128 x 256-tile kernel that runs TWO
+ * 4-wave workgroups per CU (one's C-tile stores run under the other's MFMA loop) stages its weight operand per wave and per K half in whole
+ * cache lines (csrc/gemm_k2.hip).  `B_plain` ([N][K], torch's layout) is used for the shapes that kernel does not take (K % 64 != 0, M < 128,
+ * N < 256, fp32): same results either way (same MFMA shape and K order: bit-identical to csmae_gemm).  The dX products (transB = 1) reach the
+ * same kernel through csmae_gemm: W[K][N] is K-strided with 128-B row segments per wave by nature.  csmae_gemm_k2_mode(nn, nt) switches the
+ * two uses off / on (A/B aid, default on).  timm Block call sites: MAE_ViT_Baseline.py:160-188. */
+int csmae_gemm_ks(int dtype, long long M, long long N, long long K, const void* A, long long lda, const void* Bk, long long slab_rows,
+                  const void* B_plain, long long ldb_plain, void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
+                  void* aux, long long ldaux, const void* resid, long long ldr, void* stream);
+/* desc: device int64 [count][3] = {offset (elements) of weight i in src AND dst, out-features N, in-features K (K % 64 == 0)}; one launch of
+ * (max_blocks, count) workgroups */
+int csmae_weights_kslab(int count, const long long* desc, int max_blocks, const void* src_bf16, void* dst_bf16, void* stream);
+int csmae_gemm_k2_mode(int nn, int nt);
+
 /* weight gradient of nn.Linear: dW[M=out,N=in] (fp32, contiguous) += dY[K,M]^T X[K,N]; token axis split over the chip into fp32 slabs in
  * `workspace` (>= M*N+M floats; more = more slices), folded by a deterministic reduce; db[M] (nullable) += column sums of dY, computed
  * inside the same kernel by an all-ones MFMA operand (util/misc.py:314 backward products). */

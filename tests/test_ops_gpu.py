@@ -532,6 +532,71 @@ def test_gemm_plain_epilogue_bf16_is_the_rounded_fp32_result(ops):
             assert_close(o16, ref, 1e-2, 2e-2, f"gemm plain bf16 {M}x{N}x{K} trans_b={tb}")
 
 
+def _kslab(ops, w):
+    """K-slab mirror of w [N, K] through csmae_weights_kslab, checked against the layout csmae.h states: Wk[k / 32][n][k % 32]."""
+    N, K = w.shape
+    wd = dev(w).contiguous()
+    desc = torch.tensor([[0, N, K]], dtype=torch.long, device="cuda")
+    dst = torch.zeros(N * K, device="cuda", dtype=torch.bfloat16)
+    ops.weights_kslab(desc, wd.reshape(-1), dst)
+    assert torch.equal(dst, wd.view(N, K // 32, 32).permute(1, 0, 2).contiguous().view(-1)), "csmae_weights_kslab layout"
+    return dst
+
+
+@pytest.mark.parametrize("mnk", [(128, 256, 64), (130, 256, 128), (300, 264, 192), (1000, 768, 768), (257, 512, 512), (515, 2304, 768), (2100, 520, 1024)])
+def test_gemm_two_workgroups_per_cu_kernel_is_bit_identical(ops, mnk):
+    """csrc/gemm_k2.hip (128 x 256 tiles, two 4-wave workgroups per CU; forward products through csmae_gemm_ks with the K-slab weight mirror, dX
+    products through csmae_gemm) against the one-workgroup kernels: same MFMA shape, same K order -> the same bits, for every epilogue, ragged
+    M / N, bf16 and fp32 outputs; and against fp32 torch on the same bf16 operands."""
+    import csmae_hip
+    from csmae_hip import EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID
+    lib = csmae_hip.load()
+    M, N, K = mnk
+    a = dev(rnd(M, K, seed=70).to(torch.bfloat16))
+    w = (rnd(N, K, seed=71) * 0.05).to(torch.bfloat16)
+    wk, wd, wt = _kslab(ops, w), dev(w), dev(w.t().contiguous())
+    bias = dev(rnd(N, seed=72))
+    resid = dev(rnd(M, N, seed=73).to(torch.bfloat16))
+    codes = torch.randint(0, 255, (M, N), dtype=torch.uint8, generator=torch.Generator().manual_seed(74)).cuda()
+    ref = a.float() @ wd.float().t()
+    try:
+        for epi, odt in ((EPI_NONE, torch.bfloat16), (EPI_NONE, torch.float32), (EPI_RESID, torch.bfloat16), (EPI_GELU, torch.bfloat16), (EPI_DGELU, torch.bfloat16)):
+            for layout in ("nt", "nn"):
+                outs = []
+                for mode in (2, 0):
+                    lib.csmae_gemm_k2_mode(mode, mode)
+                    out = torch.full((M, N), float("nan"), device="cuda", dtype=odt)
+                    aux = codes.clone() if epi == EPI_DGELU else (torch.zeros(M, N, device="cuda", dtype=torch.uint8) if epi == EPI_GELU else None)
+                    kw = dict(bias=None if epi == EPI_DGELU else bias, epilogue=epi, aux=aux, resid=resid if epi == EPI_RESID else None)
+                    if layout == "nt":
+                        ops.gemm_ks(a, wk, wd, out, **kw)
+                    else:
+                        ops.gemm(a, wt, out, trans_b=True, **kw)
+                    outs.append((out, aux))
+                assert torch.equal(outs[0][0].view(torch.int16 if odt == torch.bfloat16 else torch.int32), outs[1][0].view(torch.int16 if odt == torch.bfloat16 else torch.int32)), \
+                    f"k2 vs one-workgroup kernel {layout} epi {epi} {odt} {mnk}"
+                if epi == EPI_GELU:
+                    assert torch.equal(outs[0][1], outs[1][1]), f"gelu' codes {layout} {mnk}"
+                if epi == EPI_NONE:
+                    assert_close(outs[0][0], ref + bias, 1e-2, 2e-2, f"k2 {layout} {mnk}")
+                elif epi == EPI_RESID:
+                    assert_close(outs[0][0], ref + bias + resid.float(), 1e-2, 2e-2, f"k2 resid {layout} {mnk}")
+    finally:
+        lib.csmae_gemm_k2_mode(1, 2)   # the defaults (csrc/gemm.hip)
+
+
+def test_gemm_ks_falls_back_to_the_plain_weight(ops):
+    """Shapes the two-workgroups kernel does not take (K % 64 != 0, M < 128, N < 256, fp32 operands) go through csmae_gemm with the plain weight."""
+    for M, N, K, dt_ in ((64, 256, 128, torch.bfloat16), (256, 128, 128, torch.bfloat16), (256, 256, 96, torch.bfloat16), (256, 256, 128, torch.float32)):
+        a = dev(rnd(M, K, seed=75).to(dt_))
+        w = dev((rnd(N, K, seed=76) * 0.05).to(dt_))
+        bias = dev(rnd(N, seed=77))
+        out = torch.empty(M, N, device="cuda", dtype=dt_)
+        garbage = torch.full((N * K,), float("nan"), device="cuda", dtype=torch.bfloat16)   # must not be read
+        ops.gemm_ks(a, garbage, w, out, bias=bias)
+        assert_close(out, a.float() @ w.float().t() + bias, 1e-2 if dt_ == torch.bfloat16 else 1e-5, 2e-2 if dt_ == torch.bfloat16 else 1e-4, f"gemm_ks fallback {M}x{N}x{K}")
+
+
 def test_gemm_gelu_epilogues_with_8bit_derivative(ops):
     """fc1 epilogue: C = gelu(x), aux = gelu'(x) stored as one byte (q = round(200 g + 26)); fc2-backward epilogue: C = acc * aux.
     The code's resolution is 5e-3, i.e. |error| <= 2.5e-3, and saturated units (gelu' = 0 or 1) are codes 26 / 226 exactly — they decode
