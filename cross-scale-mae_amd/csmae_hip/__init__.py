@@ -27,6 +27,7 @@ _SIGNATURES = {
     "csmae_gemm_ks": [I, L, L, L, P, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P],
     "csmae_weights_kslab": [I, P, I, P, P, P],
     "csmae_gemm_k2_mode": [I, I],
+    "csmae_gemm_dw_mode": [I],
     "csmae_gemm_dw": [I, L, L, L, P, L, P, L, P, P, P, L, P],
     "csmae_gemm_dw_group": [I, I, L, P, P, P, P, P, P, P, P, I, P, L, P],
     "csmae_fp8_amax": [I, L, I, P, L, P, P],

@@ -546,13 +546,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
 // A product on its own cannot fill the chip without cutting K into 10 .. 60 slices (768 x 768: 9 tiles), each of which pays a 256-KiB
 // fp32 slab store and a share of a separate reduce kernel; together the block's 108 (ViT-B encoder) / 48 (decoder) tiles need no or
 // two slices, the fold happens inside the kernel (DwFold above) and the result is accumulated straight into the fp32 gradient.
-#define DW_GROUP_MAX 8
-struct DwDesc { const void* dY; const void* X; float* dW; float* db; int M, N; long long ldy, ldx; int tiles_n, tile0; };
-struct DwGroupArgs {
-  DwDesc d[DW_GROUP_MAX];
-  int n, K, ktiles, ktiles_per_split, nsplit, total_tiles, force_cfg;
-  float* slab; float* cs_slab;
-};
 __global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
   // slice-major order: the workgroups of one K slice are neighbours (same XCD after the remap) and walk the same rows of dY / X
   const int wg = xcd_remap(blockIdx.x, ga.total_tiles * ga.nsplit);
@@ -575,7 +568,6 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
 }
 // fold of the K slices of a grouped launch: workgroup (tile, part) adds the tile's slabs in slice order and accumulates 16 rows into
 // dW (16-byte accesses along rows); part 0 of the tn == 0 tiles does the same for the bias gradient.  Ordered: bit-reproducible.
-#define DWR_PARTS 16
 __global__ __launch_bounds__(256) void dw_group_reduce_kernel(DwGroupArgs ga) {
   const int tile_id = blockIdx.x / DWR_PARTS, quarter = blockIdx.x % DWR_PARTS;
   DwDesc d = ga.d[0];
@@ -960,7 +952,13 @@ extern "C" int csmae_gemm_force_tile(int cfg) { g_force_cfg = cfg; return 0; }
 static int k2_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int g_k2_nn = k2_env("CSMAE_K2_NN", 1);
 static int g_k2_nt = k2_env("CSMAE_K2_NT", 2);
+// grouped weight-gradient launches: 0 = 256 x 256 tiles, one workgroup per CU (default) | 1 = 128 x 256 tiles, two per CU (k2_tile_tn).  Measured
+// (gpurun_out/r05k-m): alone on the chip 1 is 25 % faster at 128 slots (it spreads over all 256 CUs), 0-8 % slower at 160 / 256; in the step
+// +0.55 ms at the best slot setting (21.85 vs 21.30 ms): the main chain loses more to 12 DMA pieces per wave and K step on every CU than its
+// LayerNorm / attention kernels gain from finding half a CU free.  Kept as an option (csmae_gemm_dw_mode) with its tests.
+static int g_k2_dw = k2_env("CSMAE_K2_DW", 0);
 extern "C" int csmae_gemm_k2_mode(int nn, int nt) { g_k2_nn = nn; g_k2_nt = nt; return 0; }
+extern "C" int csmae_gemm_dw_mode(int k2) { g_k2_dw = k2; return 0; }
 int gemm_force_cfg() { return g_force_cfg; }
 static bool k2_wanted(int mode, int epilogue, long long K) { return mode >= 2 || (mode == 1 && (epilogue == EPI_GELU || epilogue == EPI_DGELU || K <= 512)); }
 bool gemm_k2_nn_wanted(int epilogue, long long K) { return k2_wanted(g_k2_nn, epilogue, K); }
@@ -1118,6 +1116,14 @@ extern "C" int csmae_gemm_dw_group(int dtype, int count, long long K, const void
     return CSMAE_OK;
   }
   DwGroupArgs ga;
+  if (g_k2_dw) {   // weight gradients on the two-workgroups-per-CU kernel (gemm_k2.hip k2_tile_tn)
+    for (int i = 0; i < count; ++i) {
+      DwDesc& d = ga.d[i];
+      d.dY = dY[i]; d.X = X[i]; d.dW = dW[i]; d.db = db ? db[i] : nullptr; d.M = (int)M[i]; d.N = (int)N[i]; d.ldy = ldy[i]; d.ldx = ldx[i];
+    }
+    ga.n = count; ga.K = (int)K; ga.force_cfg = 0; ga.ktiles = cdiv(K, 64);
+    return gemm_k2_launch_dw(ga, count, slots <= 0 ? 128 : slots, workspace, ws_elems, (hipStream_t)stream);
+  }
   int tiles = 0;
   for (int i = 0; i < count; ++i) {
     DwDesc& d = ga.d[i];

@@ -498,10 +498,23 @@ __device__ __forceinline__ void epilogue_rows_bf16_plain(const GemmArgs& p, void
 // phase timestamps of one workgroup (tuning aid, only in -DGEMM_TIMING builds: tools/gemm_phase_timing.py)
 #ifdef GEMM_TIMING
 static __device__ unsigned long long g_gemm_ts[8];   // one per translation unit (no relocatable device code): csmae_debug_gemm_ts / csmae_debug_k2_ts
-#define GTS(i) do { if (blockIdx.x == 300 && threadIdx.x == 0) g_gemm_ts[i] = __builtin_readcyclecounter(); } while (0)
+#ifndef GTS_BLOCK
+#define GTS_BLOCK 300
+#endif
+#define GTS(i) do { if (blockIdx.x == GTS_BLOCK && threadIdx.x == 0) g_gemm_ts[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define GTS(i)
 #endif
+// grouped weight-gradient launches (csmae_gemm_dw_group): descriptor table passed by value
+#define DW_GROUP_MAX 8
+struct DwDesc { const void* dY; const void* X; float* dW; float* db; int M, N; long long ldy, ldx; int tiles_n, tile0; };
+struct DwGroupArgs {
+  DwDesc d[DW_GROUP_MAX];
+  int n, K, ktiles, ktiles_per_split, nsplit, total_tiles, force_cfg;
+  float* slab; float* cs_slab;
+};
+#define DWR_PARTS 16
+int gemm_k2_launch_dw(DwGroupArgs& ga, int count, int slots, float* workspace, long long ws_elems, hipStream_t st);   // gemm_k2.hip: 128 x 256 tiles, two workgroups per CU
 // host-side hooks shared by the two translation units
 int gemm_force_cfg();                 // csmae_gemm_force_tile's value (-1 = heuristic)
 bool gemm_k2_nn_wanted(int epilogue, long long K);   // policy of csmae_gemm_k2_mode (gemm.hip)

@@ -315,3 +315,283 @@ extern "C" int csmae_weights_kslab(int count, const long long* desc, int max_blo
   return csmae_check_launch("csmae_weights_kslab");
 }
 
+
+// ------------------------------------------------------------------------------------ weight gradients on the two-workgroups-per-CU structure
+// dW[M = out][N = in] += sum_k dY[k][m] X[k][n]: both operands K-strided (token-major), i.e. every fragment is two transposing reads
+// (ds_read_b64_tr_b16).  The one-workgroup kernel (k64_tile<true, true>) leaves those reads to the compiler and runs 3 000 - 3 500 clocks per K
+// step against 2 300 for the K-contiguous kernels (tools/dw_cycles.py); it also owns its CU for the 200 - 500 us of a launch, so that the
+// main chain's LayerNorm / attention kernels run on the CUs that are left.  Here: the k2 geometry (128 x 256 tile, four waves side by side
+// along N, wave-private B ring, 80 KiB) with every LDS read issued from inline asm and counted by hand.  lgkmcnt is a 4-bit counter and a K step
+// has 48 reads per wave, so an A fragment is re-read FOUR rows after the row that consumed it (for the row four rows ahead) instead of at
+// once: at most 3 fragment pairs and one 8-read B burst are younger than the read a row waits for (<= 14).  The step's one barrier sits behind
+// row 13 (the last read of A_j was issued behind row 11); A_{j+2} is fetched behind it.
+//   A image [64 k][128 m]: 256-B rows, piece = 4 k-rows x 256 B, 32-B granule swizzle g ^ tr_key(k-row) (8 granules: the 8 k-rows one LDS
+//   cycle of a transposing read touches fall on 8 distinct slots of the 256-B bank row).  B halves as in k2_tile<TB = true>.
+struct DwFold2 { float* slab; float* cs_slab; int nsplit; int slot; int nslots; };
+#define K2_LDS_BYTES (2 * 64 * 128 * 2 + 4 * 3 * 32 * 64 * 2)   // 80 KiB
+template <bool CS>   // CS: this tile also sums dY over the tokens (bias gradient; the tn == 0 tiles) — an instantiation of its own keeps the other tiles' loop free of branches
+__device__ __forceinline__ void k2_tile_tn(char* smem, const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold2 fold) {
+  constexpr int WM = 128, WN = 64, NW = 4, FM = 8, FN = 4;
+  constexpr int ASLOT = 64 * 128 * 2, BSLOT = 32 * 64 * 2, BWAVE = 3 * BSLOT, BBASE = 2 * ASLOT;
+  static_assert(BBASE + NW * BWAVE == K2_LDS_BYTES, "LDS layout");
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = lane & 15, g = lane >> 4;
+  const int m0 = tm * 128, n0 = tn * 256, wn = w * WN;
+  GTS(0);
+  const i4_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  // A: k-row = 16 w + 4 q + (lane >> 4), 16-B chunk (lane & 15); key = (k-row & 3) | (((k-row >> 3) & 1) << 2) = (lane >> 4) | ((q >> 1) << 2)
+  unsigned avo[2], bvo[2];
+  {
+    const int kr = lane >> 4, ch = lane & 15;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int key = kr | (qq << 2);
+      avo[qq] = (unsigned)(((long long)(w * 16 + kr) * p.lda + m0 + ((((ch >> 1) ^ key) << 1) | (ch & 1)) * 8) * 2);
+    }
+  }
+  {
+    const int kr = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int qo = 0; qo < 2; ++qo) {
+      const int key = ((kr >> 1) & 1) | (qo << 1);
+      bvo[qo] = (unsigned)(((long long)kr * p.ldb + n0 + wn + ((((ch >> 1) ^ key) << 1) | (ch & 1)) * 8) * 2);
+    }
+  }
+  const unsigned aqs = (unsigned)(4 * p.lda * 2), ajs = (unsigned)(64 * p.lda * 2), bqs = (unsigned)(8 * p.ldb * 2), bhs = (unsigned)(32 * p.ldb * 2);
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+  const unsigned ldsA = lds0 + (unsigned)(w * 4) * 1024u, ldsB = lds0 + (unsigned)(BBASE + w * BWAVE);
+  auto dma_a = [&](int slot, int j, int q) {
+    lds_dma16u(rsA, avo[q >> 1] + ((unsigned)j * ajs + (unsigned)q * aqs), ldsA + (unsigned)(slot * ASLOT + q * 1024));
+  };
+  auto dma_b = [&](int slot, int u, int q) {
+    lds_dma16u(rsB, bvo[q & 1] + ((unsigned)u * bhs + (unsigned)q * bqs), ldsB + (unsigned)(slot * BSLOT + q * 1024));
+  };
+  f4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < FN; ++jj) acc[i][jj] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const int ra0 = (8 * g + (t >> 2)) * 256 + (((t >> 2) | ((g & 1) << 2)) << 5) + (t & 3) * 8;
+  const int rb0 = (8 * g + (t >> 2)) * 128 + ((((t >> 3) & 1) | ((g & 1) << 1)) << 5) + (t & 3) * 8;
+  s4_t alo[FM], ahi[FM], b0lo[FN], b0hi[FN], b1lo[FN], b1hi[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) { alo[i] = s4_t{0, 0, 0, 0}; ahi[i] = s4_t{0, 0, 0, 0}; }
+  // fragment i of K half h of the A image in `slot`: two transposing reads into the registers the fragment's last row has consumed
+  auto read_a2 = [&](int slot, int h, int i, s4_t& lo, s4_t& hi) {
+    const unsigned addr = lds0 + (unsigned)(slot * ASLOT) + (unsigned)((ra0 ^ (i << 5)) + h * 8192);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "+v"(lo) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "+v"(hi) : "v"(addr));
+  };
+  auto read_a = [&](int slot, int h, auto ic) { constexpr int i = decltype(ic)::value; read_a2(slot, h, i, alo[i], ahi[i]); };
+  auto read_b = [&](int slot, s4_t (&lo)[FN], s4_t (&hi)[FN]) {
+#pragma unroll
+    for (int jn = 0; jn < FN; ++jn) {
+      const unsigned a2 = ldsB + (unsigned)(slot * BSLOT) + (unsigned)(rb0 ^ (jn << 5));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[jn]) : "v"(a2));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi[jn]) : "v"(a2));
+    }
+  };
+  // hand-counted wait tied to the registers the next MFMAs read
+  auto wait_a2 = [&](auto n, s4_t& lo, s4_t& hi) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(decltype(n)::value)); };
+  auto wait_a = [&](auto n, auto ic) { constexpr int i = decltype(ic)::value; wait_a2(n, alo[i], ahi[i]); };
+  auto wait_b = [&](auto n, s4_t (&lo)[FN], s4_t (&hi)[FN]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]) : "n"(decltype(n)::value));
+  };
+  // bias gradient (sum over tokens of dY) on the tn == 0 tiles: wave w sums fragments 2 w and 2 w + 1 (every wave holds all eight)
+  constexpr bool do_cs = CS;
+  float cs[2] = {0.f, 0.f};
+  auto mma_row2 = [&](int i, const s4_t& al, const s4_t& ah, f4_t (&ac)[FN], s4_t (&blo)[FN], s4_t (&bhi)[FN]) {
+    const s8_t fa = join_s4(al, ah);
+#pragma unroll
+    for (int jj = 0; jj < FN; ++jj)
+      ac[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, join_s4(blo[jj], bhi[jj])), __builtin_bit_cast(bf8_t, fa), ac[jj], 0, 0, 0);
+    if (do_cs && w == (i >> 1)) {
+      const u4_t d = __builtin_bit_cast(u4_t, fa);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0 += __uint_as_float(d[e] << 16); s1 += __uint_as_float(d[e] & 0xFFFF0000u); }
+      cs[i & 1] += s0 + s1;
+    }
+  };
+  auto mma_row = [&](auto ic, s4_t (&blo)[FN], s4_t (&bhi)[FN]) { constexpr int i = decltype(ic)::value; mma_row2(i, alo[i], ahi[i], acc[i], blo, bhi); };
+  // ---- prologue (issue order chosen so that every wait of the first step has the steady state's 8 younger pieces behind what it needs)
+  const int nsteps = kt_end - kt_begin;
+  const int jb = kt_begin;   // absolute K step of the slice's first step; B half u = 2 (jb + j) + h
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_a(0, jb, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_b(0, 2 * jb, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_b(1, 2 * jb + 1, q);
+  if (nsteps >= 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_b(2, 2 * jb + 2, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_a(1, jb + 1, q);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  GTS(1);
+  static_for<4>([&](auto ic) { read_a(0, 0, ic); });   // fragments 0 .. 3 of the first half; 4 .. 7 follow behind rows 0 .. 3
+  read_b(0, b0lo, b0hi);
+  auto nx3 = [](int s, int k) { s += k; return s >= 3 ? s - 3 : s; };
+  // Reads in program order (steady state):  behind row 0: A(4), B_j^1 x 8 | rows 1 .. 3: A(5 .. 7) | rows 4 .. 7: A(8 .. 11) (second half, fragments 0 .. 3)
+  // | row 8: A(12), B_{j+1}^0 x 8 | rows 9 .. 11: A(13 .. 15) | row 12: - | row 13: barrier, A(16), A(17) (next step) | rows 14, 15: A(18), A(19).
+  // Younger reads at the wait in front of row g (each A = 2 reads): see the table in `wcnt`.
+  // DMA: B_{j+1}^1 behind rows 1, 3, 5, 7 | B_{j+2}^0 behind rows 9 .. 12 | A_{j+2} behind rows 14, 15 (two pieces each): every wait leaves 8 pieces in flight.
+  // MODE 0 steady | 2 second-to-last step (only B_{j+1}^1 left to fetch) | 3 last step
+  auto step = [&](int j, int sa, int sb, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool more = MODE < 3;
+    const int sb1 = nx3(sb, 1), sb2 = nx3(sb, 2);
+    const int ja = jb + j;
+    if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // B_j^1 has landed
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<16>([&](auto rc) {
+      constexpr int r = decltype(rc)::value, i = r & 7;
+      // ---- wait for the row's fragment (and, at the head of a half, for its B fragments)
+      constexpr int wc = (r == 0) ? 6 : (r <= 4) ? 14 : (r <= 8) ? 6 : (r <= 12) ? (more ? 14 : 6) : (r == 13) ? 4 : -1;
+      if (r == 0) { wait_a(std::integral_constant<int, wc>{}, std::integral_constant<int, 0>{}); wait_b(std::integral_constant<int, wc>{}, b0lo, b0hi); }
+      else if (r == 8) { wait_a(std::integral_constant<int, wc>{}, std::integral_constant<int, 0>{}); wait_b(std::integral_constant<int, wc>{}, b1lo, b1hi); }
+      else if (wc >= 0) wait_a(std::integral_constant<int, wc>{}, std::integral_constant<int, i>{});
+      if (r < 8) mma_row(std::integral_constant<int, i>{}, b0lo, b0hi); else mma_row(std::integral_constant<int, i>{}, b1lo, b1hi);
+      // ---- the fragment for the row four rows ahead, into the registers consumed four rows ago
+      if (r < 4) read_a(sa, 0, std::integral_constant<int, r + 4>{});                 // rows 4 .. 7: first half, fragments 4 .. 7
+      else if (r < 8) read_a(sa, 1, std::integral_constant<int, r - 4>{});            // rows 8 .. 11: second half, fragments 0 .. 3
+      else if (r < 12) read_a(sa, 1, std::integral_constant<int, r - 4>{});           // rows 12 .. 15: second half, fragments 4 .. 7
+      if (r == 0) read_b(sb1, b1lo, b1hi);
+      if (r == 8 && more) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              // B_{j+1}^0 has landed (wave-private: no barrier)
+        read_b(sb2, b0lo, b0hi);
+      }
+      if (r == 13) {
+        if (MODE == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (MODE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // own pieces of A_{j+1}
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // every read of A_j is done (the last was issued behind row 11)
+        if (more) {
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          read_a(sa ^ 1, 0, std::integral_constant<int, 0>{}); read_a(sa ^ 1, 0, std::integral_constant<int, 1>{});
+        }
+      }
+      if (r == 14 && more) read_a(sa ^ 1, 0, std::integral_constant<int, 2>{});
+      if (r == 15 && more) read_a(sa ^ 1, 0, std::integral_constant<int, 3>{});
+      // ---- DMA pieces
+      if (more && r < 8 && (r & 1)) dma_b(sb, 2 * ja + 3, r >> 1);
+      if (MODE == 0 && r >= 9 && r <= 12) dma_b(sb1, 2 * ja + 4, r - 9);
+      if (MODE == 0 && r >= 14) { dma_a(sa, ja + 2, 2 * (r - 14)); dma_a(sa, ja + 2, 2 * (r - 14) + 1); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  int j = 0, sa = 0, sb = 0;
+  for (; j < nsteps - 2; ++j, sa ^= 1, sb = nx3(sb, 2)) step(j, sa, sb, std::integral_constant<int, 0>{});
+  if (nsteps >= 2) { step(j, sa, sb, std::integral_constant<int, 2>{}); ++j; sa ^= 1; sb = nx3(sb, 2); }
+  step(j, sa, sb, std::integral_constant<int, 3>{});
+  GTS(2);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (do_cs) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { float v = cs[e]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); cs[e] = v; }
+  }
+  // ---- epilogue: one slice -> dW += acc, db += column sums; several -> dense 128 x 256 fp32 slab + column-sum partials for the ordered fold
+  constexpr int ESTR = WN + 4, LPR = WN / 4, RPP = 64 / LPR, EROWS = 32;
+  float* ew = reinterpret_cast<float*>(smem + BBASE + w * BWAVE);
+  if (fold.nsplit > 1) {
+    if (do_cs && g == 0) {
+      float* csm = fold.cs_slab + ((long long)split * fold.nslots + fold.slot) * 128;
+      csm[(2 * w) * 16 + t] = cs[0];
+      csm[(2 * w + 1) * 16 + t] = cs[1];
+    }
+    GemmArgs q = p;
+    q.M = 128; q.N = 256; q.ldc = 256; q.bias = nullptr;
+    float* mine = fold.slab + ((long long)split * fold.nslots + fold.slot) * (128 * 256);
+    epilogue_rows<float, EPI_NONE, FM, FN, WM, EROWS, ESTR, LPR, RPP>(q, mine, acc, ew, 0, wn, lane, t, g);
+    GTS(3);
+    return;
+  }
+  if (do_cs && g == 0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int m = m0 + (2 * w + e) * 16 + t;
+      if (m < p.M) p.colsum[m] += cs[e];
+    }
+  }
+  epilogue_rows<float, EPI_RESID, FM, FN, WM, EROWS, ESTR, LPR, RPP>(p, p.C, acc, ew, m0, n0 + wn, lane, t, g);   // dW = dW + acc (resid = C)
+  GTS(3);
+}
+__global__ __launch_bounds__(256, 2) void gemm_dw_group_k2_kernel(DwGroupArgs ga) {
+  const int wg = xcd_remap(blockIdx.x, ga.total_tiles * ga.nsplit);   // slice-major: the workgroups of a K slice are neighbours on an XCD
+  const int split = wg / ga.total_tiles, tile_id = wg - split * ga.total_tiles;
+  DwDesc d = ga.d[0];
+#pragma unroll
+  for (int i = 1; i < DW_GROUP_MAX; ++i) if (i < ga.n && tile_id >= ga.d[i].tile0) d = ga.d[i];
+  const int tile = tile_id - d.tile0;
+  const int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
+  const int kt_begin = split * ga.ktiles_per_split;
+  const int kt_end = min(kt_begin + ga.ktiles_per_split, ga.ktiles);
+  GemmArgs p;
+  p.A = d.dY; p.B = d.X; p.C = d.dW; p.bias = nullptr; p.aux = nullptr; p.resid = d.dW;
+  p.lda = d.ldy; p.ldb = d.ldx; p.ldc = d.N; p.ldaux = 0; p.ldr = d.N;
+  p.M = d.M; p.N = d.N; p.K = ga.K;
+  p.c_dtype = CSMAE_F32; p.epi = EPI_RESID; p.splitk = ga.nsplit; p.tiles_m = 0; p.tiles_n = d.tiles_n; p.ktiles = ga.ktiles; p.ktiles_per_split = ga.ktiles_per_split;
+  p.a_bytes = (unsigned)((long long)ga.K * d.ldy * 2); p.b_bytes = (unsigned)((long long)ga.K * d.ldx * 2);
+  p.force_cfg = 0; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = 0; p.q_out = nullptr;
+  __shared__ __attribute__((aligned(16))) char smem[K2_LDS_BYTES];
+  const DwFold2 fold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles};
+  if (d.db != nullptr && tn == 0) k2_tile_tn<true>(smem, p, tm, tn, split, kt_begin, kt_end, fold);
+  else k2_tile_tn<false>(smem, p, tm, tn, split, kt_begin, kt_end, fold);
+}
+// ordered fold of the K slices (128 x 256 slabs): workgroup (tile, part) adds 128 / DWR_PARTS rows in slice order into dW; part 0 of the tn == 0 tiles the bias gradient
+__global__ __launch_bounds__(256) void dw_group_reduce_k2_kernel(DwGroupArgs ga) {
+  const int tile_id = blockIdx.x / DWR_PARTS, part = blockIdx.x % DWR_PARTS;
+  DwDesc d = ga.d[0];
+#pragma unroll
+  for (int i = 1; i < DW_GROUP_MAX; ++i) if (i < ga.n && tile_id >= ga.d[i].tile0) d = ga.d[i];
+  const int tile = tile_id - d.tile0;
+  const int tm = tile / d.tiles_n, tn = tile - tm * d.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 256;
+  const int c4 = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+  const long long sstride = (long long)ga.total_tiles * 128 * 256;
+  const float* base = ga.slab + (long long)tile_id * 128 * 256;
+  const int n = n0 + c4 * 4;
+  constexpr int RPB = 128 / DWR_PARTS;
+#pragma unroll
+  for (int r = part * RPB + r0; r < part * RPB + RPB; r += 4) {
+    const int m = m0 + r;
+    if (m >= d.M || n >= d.N) continue;
+    float* dst = d.dW + (long long)m * d.N + n;
+    f4_t a = *reinterpret_cast<f4_t*>(dst);
+    for (int sl = 0; sl < ga.nsplit; ++sl) a += *reinterpret_cast<const f4_t*>(base + sl * sstride + r * 256 + c4 * 4);
+    *reinterpret_cast<f4_t*>(dst) = a;
+  }
+  if (part == 0 && tn == 0 && d.db != nullptr && threadIdx.x < 128) {
+    const int m = m0 + threadIdx.x;
+    if (m < d.M) {
+      float a = d.db[m];
+      for (int sl = 0; sl < ga.nsplit; ++sl) a += ga.cs_slab[((long long)sl * ga.total_tiles + tile_id) * 128 + threadIdx.x];
+      d.db[m] = a;
+    }
+  }
+}
+// ga.d[i] filled by the caller except tiles_n / tile0; `slots` counts whole-CU workgroups (the one-workgroup kernel's unit): twice as many here
+int gemm_k2_launch_dw(DwGroupArgs& ga, int count, int slots, float* workspace, long long ws_elems, hipStream_t st) {
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    DwDesc& d = ga.d[i];
+    d.tiles_n = cdiv(d.N, 256); d.tile0 = tiles;
+    tiles += cdiv(d.M, 128) * d.tiles_n;
+  }
+  for (int i = count; i < DW_GROUP_MAX; ++i) ga.d[i] = ga.d[0];
+  ga.total_tiles = tiles;
+  long long S = (2LL * slots) / tiles;
+  if (S > ga.ktiles / 8) S = ga.ktiles / 8;
+  const long long per_slice = (long long)tiles * (128 * 256 + 128);
+  if (S > ws_elems / per_slice) S = ws_elems / per_slice;
+  if (S < 1) S = 1;
+  ga.ktiles_per_split = cdiv(ga.ktiles, S);
+  ga.nsplit = cdiv(ga.ktiles, ga.ktiles_per_split);
+  ga.slab = workspace; ga.cs_slab = workspace + (long long)ga.nsplit * tiles * 128 * 256;
+  if (ga.nsplit > 1 && ws_elems < ga.nsplit * per_slice) { csmae_set_error("csmae_gemm_dw_group: workspace too small"); return CSMAE_ERR_ARG; }
+  hipLaunchKernelGGL(gemm_dw_group_k2_kernel, dim3(tiles * ga.nsplit), dim3(256), 0, st, ga);
+  if (ga.nsplit > 1) hipLaunchKernelGGL(dw_group_reduce_k2_kernel, dim3(tiles * DWR_PARTS), dim3(256), 0, st, ga);
+  return csmae_check_launch("csmae_gemm_dw_group");
+}

@@ -68,6 +68,7 @@ int csmae_gemm_ks(int dtype, long long M, long long N, long long K, const void* 
  * (max_blocks, count) workgroups */
 int csmae_weights_kslab(int count, const long long* desc, int max_blocks, const void* src_bf16, void* dst_bf16, void* stream);
 int csmae_gemm_k2_mode(int nn, int nt);
+int csmae_gemm_dw_mode(int k2);   /* csmae_gemm_dw_group on the 256 x 256 one-workgroup kernel (0, default) or the two-workgroups-per-CU one (1): measured slower in the step, kept as an option */
 
 /* weight gradient of nn.Linear: dW[M=out,N=in] (fp32, contiguous) += dY[K,M]^T X[K,N]; token axis split over the chip into fp32 slabs in
  * `workspace` (>= M*N+M floats; more = more slices), folded by a deterministic reduce; db[M] (nullable) += column sums of dY, computed

@@ -121,6 +121,34 @@ def test_gemm_dw_split_slabs(ops, dtype, mnk):
     assert_close(acc, acc0 + dY.float().t() @ X.float(), 1e-4, 1e-3 * K ** 0.5 / 30, "gemm_dw padded")
 
 
+@pytest.mark.parametrize("case", [(512, [(256, 256)], 4, 0), (1000, [(256, 512), (520, 264)], 16, 8), (4096, [(768, 768), (2304, 768)], 160, 0), (640, [(1024, 1024), (1024, 4096)], 256, 0)])
+def test_gemm_dw_group_two_workgroups_per_cu_kernel(ops, case):
+    """csmae_gemm_dw_group through k2_tile_tn (csmae_gemm_dw_mode(1): 128 x 256 tiles, hand-counted transposing reads): dW += dY^T X and db += colsum(dY)
+    against fp32 torch on the same bf16 operands, one and several K slices, ragged sizes and padded rows, deterministic (ordered fold)."""
+    import csmae_hip
+    lib = csmae_hip.load()
+    K, prods, slots, pad = case
+    ws = torch.empty(64 << 20, device="cuda")
+    items = []
+    for i, (M, N) in enumerate(prods):
+        dy = dev(rnd(K, M + pad, seed=300 + i).to(torch.bfloat16))[:, :M]
+        x = dev(rnd(K, N + pad, seed=310 + i).to(torch.bfloat16))[:, :N]
+        items.append((dy, x))
+    try:
+        lib.csmae_gemm_dw_mode(1)
+        runs = []
+        for _ in range(2):
+            outs = [(torch.full((dy.shape[1], x.shape[1]), 0.25, device="cuda"), torch.full((dy.shape[1],), 0.25, device="cuda")) for dy, x in items]
+            ops.DwGroup([(dy, x, dw, db) for (dy, x), (dw, db) in zip(items, outs)], ws).launch(slots)
+            runs.append(outs)
+        for (dy, x), (dw, db), (dw2, db2) in zip(items, runs[0], runs[1]):
+            assert torch.equal(dw, dw2) and torch.equal(db, db2), "weight-gradient fold is not deterministic"
+            assert_close(dw, 0.25 + dy.float().t() @ x.float(), 1e-4, 1e-3 * K ** 0.5, f"k2 dW {tuple(dw.shape)} K={K}")
+            assert_close(db, 0.25 + dy.float().sum(0), 1e-4, 1e-3 * K ** 0.5, f"k2 db {tuple(dw.shape)} K={K}")
+    finally:
+        lib.csmae_gemm_dw_mode(0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("slots", [4, 40, 160])
 def test_gemm_dw_group(ops, dtype, slots):
