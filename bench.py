@@ -103,6 +103,71 @@ def cpu_baseline(seconds_budget=30.0):
                        f"{threads} torch threads of {os.cpu_count()} host cores")
 
 
+class ChipWatch:
+    """Shader clock and board power over the timed region, sampled from sysfs (hwmon freq1_input / power1_average of this rank's GPU) on a host
+    thread: the chip clocks to its power budget (MI355X_MICROARCH.md, DVFS), boxes of the pool differ by a few %, and a line that carries its
+    own clock can be told apart from a slower kernel.  Best effort: fields are null where sysfs does not offer them."""
+
+    def __init__(self, device_index):
+        import glob
+        self.freq = self.power = None
+        self.samples = []
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}".lower() if hasattr(props, "pci_bus_id") else None
+        except Exception:
+            want = None
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+            real = os.path.realpath(dev)
+            hw = glob.glob(os.path.join(dev, "hwmon", "hwmon*"))
+            if not hw or not os.path.exists(os.path.join(hw[0], "freq1_input")):
+                continue
+            cards.append((real, hw[0]))
+        pick = next((c for c in cards if want and want in c[0].lower()), cards[device_index] if device_index < len(cards) else (cards[0] if cards else None))
+        if pick:
+            self.freq = os.path.join(pick[1], "freq1_input")
+            self.power = next((q for q in (os.path.join(pick[1], n) for n in ("power1_average", "power1_input")) if os.path.exists(q)), None)
+        self._stop = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append((self._read(self.freq), self._read(self.power)))
+                self._stop.wait(0.02)
+        self._th = threading.Thread(target=loop, daemon=True)
+        if self.freq:
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.freq:
+            self._th.join()
+
+    def summary(self):
+        f = [a / 1e6 for a, _ in self.samples if a]
+        w = [b / 1e6 for _, b in self.samples if b]
+        return {"clock_mhz_mean": round(sum(f) / len(f), 1) if f else None, "clock_mhz_min": round(min(f), 1) if f else None,
+                "power_w_mean": round(sum(w) / len(w), 1) if w else None, "samples": len(self.samples)}
+
+
+def chip_info(device_index):
+    p = torch.cuda.get_device_properties(device_index)
+    return {"gpu_name": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2 ** 30, 1)}
+
+
 SETTLE_STEPS = 10
 
 
@@ -145,6 +210,7 @@ def main():
     if csmae_hip.source_hash() != csrc_hash():
         log(f"WARNING: libcsmae_hip.so was built from csrc {csmae_hip.source_hash()[:16]}, the tree holds {csrc_hash()[:16]} (stale build?)")
 
+    from csmae_hip import debug_opt as csmae_dbg   # CSMAE_DEBUG="key=value,...": experiment knobs
     factory, size, patch, chans, pbatch, gflop = PRESETS[a.preset]
     if a.batch is None:
         a.batch = pbatch
@@ -154,7 +220,9 @@ def main():
     torch.manual_seed(0 + rank)  # main_pretrain.py:368
     samples = torch.randn(a.batch, chans, size, size, device=device)
 
-    main_cus = os.environ.get("CSMAE_MAIN_CUS")   # experiment aid (CU partition): "lo:hi" = mask bits of the main stream
+    if csmae_dbg("bench_stream"):   # experiment aid (CU partition): the whole step on a non-blocking stream of its own, nothing on
+        torch.cuda.set_stream(torch.cuda.Stream())   # the legacy null stream — a CU-masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags)
+    main_cus = csmae_dbg("main_cus")   # ... "lo:hi" = mask bits of the main stream
     if main_cus:
         from csmae_hip import ops as _ops
         lo, hi = (int(v) for v in main_cus.split(":"))
@@ -184,11 +252,13 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    mine = time.perf_counter() - t0
+    watch = ChipWatch(local)
+    with watch:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step()
+        fence()
+        mine = time.perf_counter() - t0
     elapsed = torch.tensor([mine], device=device, dtype=torch.float64)
     dp_check = None
     if world > 1:
@@ -254,7 +324,7 @@ def main():
         log("kernel timing pass done")
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["work"] for v in summ.values())
-        kernel = dict(name="GEMM family: gemm_bf16_k64_kernel + gemm_dw_group_kernel (MFMA 16x16x32 bf16)" + (" + gemm_fp8_kernel (MFMA 16x16x128 f8f6f4)" if a.dtype == "fp8" else "") +
+        kernel = dict(name="GEMM family: gemm_bf16_k2_kernel (128x256 tiles, two workgroups per CU) + gemm_bf16_k64_kernel + gemm_dw_group_kernel (256x256 tiles) (MFMA 16x16x32 bf16)" + (" + gemm_fp8_kernel (MFMA 16x16x128 f8f6f4)" if a.dtype == "fp8" else "") +
                       "; serialised on one stream for the HIP-event timing (every launch alone on the chip; in the overlapped step the weight-gradient launches are held to 160 workgroups)", launches_per_step=sum(v["launches"] for v in summ.values()),
                       ms_per_step=round(tot_ms, 3), tflops=round(tot_fl / tot_ms / 1e9, 1),
                       by_layout={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=round(v["work"] / v["ms"] / 1e9, 1)) for k, v in summ.items()})
@@ -284,6 +354,7 @@ def main():
                        "loss": a.loss, "batch_per_gpu": a.batch, "global_batch": a.batch * world, "input": [chans, size, size], "parallelism": f"dp{world}",
                        "headline_config": bool(scale)},
             "loss": round(final_loss, 5), "library_source_sha256": csmae_hip.source_hash()[:16],
+            "chip": dict(chip_info(local), **watch.summary()),
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic if (a.preset == "base" and a.dtype == "bf16" and scale) else None, "algorithmic_gflop_per_image": gflop, "dominant_kernel": kernel},
         }

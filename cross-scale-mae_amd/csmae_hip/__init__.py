@@ -82,6 +82,16 @@ _SIGNATURES = {
     "csmae_stream_destroy": [P],
 }
 
+def debug_opt(name: str, default=None):
+    """One gate for the settled A/B aids and experiment knobs: CSMAE_DEBUG="key[=value],key[=value],..." (INTEGRATION.md lists the keys; the C
+    library reads the same variable).  Returns the value ("1" for a bare key) or `default`."""
+    for item in os.environ.get("CSMAE_DEBUG", "").split(","):
+        k, _, v = item.strip().partition("=")
+        if k == name:
+            return v or "1"
+    return default
+
+
 _lib = None
 
 

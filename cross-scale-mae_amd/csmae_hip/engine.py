@@ -25,7 +25,8 @@ from typing import Dict, Optional
 
 import torch
 
-from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, SSIM_KINDS, ops
+from . import BF16, EPI_ATOMIC, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID, F32, SSIM_KINDS, debug_opt, ops
+from . import trace
 
 _FROZEN = ("encoder_pos_embed", "decoder_pos_embed")
 
@@ -228,9 +229,9 @@ class Engine:
         self.fp8 = act_dtype == "fp8"
         self._fp8_site = 0
         self._fp8_cur = None    # (site, fp8 bytes or None) of the residual gradient the next block's fc2-backward product reads
-        self._fp8_fuse_lnb = not os.environ.get("CSMAE_FP8_NO_FUSE_LNB")
-        self._fp8_fuse_attn = not os.environ.get("CSMAE_FP8_NO_FUSE_ATTN")   # A/B aid: attention's fp8 copies by separate quantisation passes
-        self._fp8_fuse = not os.environ.get("CSMAE_FP8_NO_FUSE")   # A/B aid: every fp8 operand through the separate quantisation pass
+        self._fp8_fuse_lnb = not debug_opt("fp8_no_fuse_lnb")
+        self._fp8_fuse_attn = not debug_opt("fp8_no_fuse_attn")   # A/B aid: attention's fp8 copies by separate quantisation passes
+        self._fp8_fuse = not debug_opt("fp8_no_fuse")   # A/B aid: every fp8 operand through the separate quantisation pass
         if self.fp8:
             act_dtype = torch.bfloat16
         if self.device.type != "cuda":
@@ -260,26 +261,27 @@ class Engine:
         self.gen = 0            # forward() counter: an autograd node may only run the backward of the forward it belongs to
         self._gen_done = -1
         self.side, self.main, self.aux = None, None, None
+        self._ks_event, self._ks_pending = None, False
         self._fwd_streams = []
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
-        self.use_ks = not os.environ.get("CSMAE_NO_KSLAB")   # A/B aid: forward products through csmae_gemm (one 256 x 256 workgroup per CU) instead of csmae_gemm_ks
-        self._dw_slots = int(os.environ.get("CSMAE_DW_SLOTS", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
+        self.use_ks = not debug_opt("no_kslab")   # (CSMAE_DEBUG=no_kslab: forward products through csmae_gemm with the plain weight mirror; no K-slab mirror is kept)
+        self._dw_slots = int(debug_opt("dw_slots", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
         # 128 workgroups = 4 / 8 whole K slices of its 32- and 16-tile launches (160 -> 128: -0.15 .. -0.3 ms per step; 64: +1.4 ms)
-        se = os.environ.get("CSMAE_DW_SLOTS_ED", "" if "CSMAE_DW_SLOTS" in os.environ else "160,128")
+        se = os.environ.get("CSMAE_DW_SLOTS_ED", "" if debug_opt("dw_slots") else "160,128")
         self._dw_slots_ed = tuple(int(v) for v in se.split(",")) if se else None
         # weight gradients of a block: "half" = two grouped launches (fc2 + fc1 once dpre exists, proj + qkv after attention backward),
         # "block" = ONE launch when its tiles fit the slots (ViT-B: 108 encoder tiles, no K slice; 48 decoder tiles, 3 slices: 2.5 GB
         # less slab traffic per step, no fold kernel for the encoder — and measured 0.13 ms SLOWER per step on three boxes: the step is
         # bound by the main chain, which runs beside a 300-us launch worse than beside two shorter ones), "none" = one per product
-        self._dw_mode = os.environ.get("CSMAE_DW_GROUP", "half")
+        self._dw_mode = debug_opt("dw_group", "half")
         self._dw_rot = self._dw_mode != "half0"   # A/B aid: "half0" = the two-launch mode with its outgoing gradient written over the incoming one (a wait per buffer)
         if self._dw_mode == "half0":
             self._dw_mode = "half"
         if self._dw_mode not in ("block", "block_enc", "block_dec", "half", "none"):
-            raise ValueError(f"CSMAE_DW_GROUP={self._dw_mode!r}: block, block_enc, block_dec, half or none")
+            raise ValueError(f"CSMAE_DEBUG dw_group={self._dw_mode!r}: block, block_enc, block_dec, half or none")
         sl = flat.slots
         goff = lambda names: torch.tensor([[sl[n + ".weight"][0], sl[n + ".bias"][0]] for n in names], dtype=torch.long, device=self.device)
         self._goff_e = goff([f"encoder.{i}.norm{k}" for i in range(cfg["Ne"]) for k in (1, 2)])
@@ -326,8 +328,23 @@ class Engine:
             f.ks_stamp = None
         stamp = (f.lp_stamp, f.raw_writes)
         if stamp != f.ks_stamp and f.ks_desc.shape[0]:
-            ops.weights_kslab(f.ks_desc, f.w_lp, f.w_ks)
+            # on the auxiliary stream, under the stem (crop, masking, patch embedding: ~0.2 ms before the first block needs a weight): the
+            # 90-us launch is off the main chain; _ks_wait() orders the first consumer behind it
+            cur = torch.cuda.current_stream()
+            if self.aux is not None and ops._timer is None:
+                self.aux.wait_stream(cur)   # the optimizer's writes to the bf16 mirror
+                ops.weights_kslab(f.ks_desc, f.w_lp, f.w_ks, st=self.aux.cuda_stream)
+                self._ks_event = self._ks_event or torch.cuda.Event()
+                self._ks_event.record(self.aux)
+                self._ks_pending = True
+            else:
+                ops.weights_kslab(f.ks_desc, f.w_lp, f.w_ks)
             f.ks_stamp = stamp
+
+    def _ks_wait(self):
+        if self._ks_pending:
+            torch.cuda.current_stream().wait_event(self._ks_event)
+            self._ks_pending = False
 
     def _w_pe(self):
         if self.T == BF16 and self.Pp != self.cfg["P"]:
@@ -491,7 +508,7 @@ class Engine:
     def _new_side(self):
         """The weight-gradient stream.  CSMAE_DW_CUS=n confines it to n compute units of every XCD (ops.cu_masked_stream) instead of letting its
         160-workgroup launches time-slice whole CUs with the main chain; the forward's second-view stream is then a stream of its own."""
-        n = int(os.environ.get("CSMAE_DW_CUS", "0"))
+        n = int(debug_opt("dw_cus", "0"))
         if n <= 0:
             return torch.cuda.Stream()
         self._side_masked = True
@@ -633,6 +650,11 @@ class Engine:
     # ------------------------------------------------------------------ forward
     def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool,
                 img1: Optional[torch.Tensor] = None):
+        with trace.range_("csmae.forward"):
+            return self._forward(imgs, mask_ratio, noise, box_host, training, img1)
+
+    def _forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool,
+                 img1: Optional[torch.Tensor] = None):
         """`img1`: the second view given explicitly (MAE_ViT_MsLd_PAIRED, MAE_ViT_MsLd.py:79-146) instead of the random resized crop of `imgs`."""
         c = self.cfg
         N = imgs.shape[0]
@@ -664,6 +686,7 @@ class Engine:
         ops.patch_gather(img0, img1, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
         ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
         ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep, st=st)
+        self._ks_wait()   # the K-slab weight mirrors (made under the stem on the auxiliary stream) before the first block and before the view streams fork
         latent = ws.enc["x"][c["Ne"]]
         lat_heads = ws.lat32 if ws.lat32 is not None else latent   # what the loss heads read (fp32)
         main = torch.cuda.current_stream()
@@ -837,6 +860,7 @@ class Engine:
         self.st = st = ops.stream()
         L, D = c["L"], c["D"]
         self._refresh_lp()
+        self._ks_wait()
         self._fp8_begin()
         ws.noise.copy_(noise)
         ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
@@ -864,6 +888,7 @@ class Engine:
         ws, P = self.ws, self.flat.P
         self.st = st = ops.stream()
         self._refresh_lp()
+        self._ks_wait()
         self._fp8_begin()
         lat = latent.reshape(N * Te, D).to(torch.float32).contiguous()
         if self.T == BF16:
@@ -892,9 +917,10 @@ class Engine:
     def backward(self, gout: torch.Tensor, accumulate: bool, gen: Optional[int] = None):
         """Engine._backward, optionally with the main chain confined to a CU range for the length of the reverse pass (experiment aid,
         DESIGN §5 "CU partition": CSMAE_BWD_MAIN_CUS=lo:hi mask bits; the forward pass keeps the whole chip)."""
-        rng = os.environ.get("CSMAE_BWD_MAIN_CUS")
+        rng = debug_opt("bwd_main_cus")
         if not rng:
-            return self._backward(gout, accumulate, gen)
+            with trace.range_("csmae.backward"):
+                return self._backward(gout, accumulate, gen)
         lo, hi = (int(v) for v in rng.split(":"))
         outer, inner = torch.cuda.current_stream(), ops.cu_masked_stream(lo, hi)
         inner.wait_stream(outer)
@@ -931,7 +957,7 @@ class Engine:
             # The gradient clear (455 MB for ViT-B) runs on the weight-gradient stream, which is idle between the forward and the backward
             # pass, beside the reconstruction head's backward on the main stream: every weight-gradient launch follows it in stream order,
             # the main stream's own writers into the buffer (BatchNorm / LayerNorm / token gradients) wait for `zeroed` below.
-            if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN") or os.environ.get("CSMAE_ZERO_MAIN"):   # (CSMAE_ZERO_MAIN: A/B aid)
+            if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN") or debug_opt("zero_main"):   # (CSMAE_ZERO_MAIN: A/B aid)
                 self.flat.g[: self.flat.total].zero_()
             else:
                 self.side.wait_stream(self.main)
@@ -944,6 +970,7 @@ class Engine:
         head_start = self._event()
         head_start.record(self.main)
         kind, npx = c["loss"], c["norm_pix"]
+        trace.push("csmae.backward.junction")   # loss heads' backward up to the decoder's last LayerNorm
         # reconstruction head
         extra = None
         ssim = SSIM_KINDS.get(kind)
@@ -995,6 +1022,8 @@ class Engine:
                 ej.record(self.main)
                 self._dw_group([(ws.dpred_lp, ws.emb_lp, "decoder_pred")], ready=ej)
                 self._dw_group([(ws.dv, ws.r, "predictor.3"), (ws.dr, ws.pin, "predictor.0")], ready=ej)
+        trace.pop()
+        trace.push("csmae.backward.decoder")
         # decoder
         lp_stream = self.res_dtype != torch.float32   # bf16 residual-gradient stream: the ping-pong buffers are the stream itself
         pd, Nd2 = ws.ln_part_d, 2 * c["Nd"]
@@ -1021,6 +1050,8 @@ class Engine:
         if dp is not None:   # decoder + heads are final: their all-reduce overlaps the encoder backward.  The exchange stream waits for
             # the weight-gradient stream itself (`also`): the main chain does not stop for the block's grouped launches to finish
             dp.grads_ready(self.flat, "tail", also=self.side if not (ops._timer is not None or os.environ.get("CSMAE_DW_MAIN")) else None)
+        trace.pop()
+        trace.push("csmae.backward.encoder")
         latent = ws.lat32 if ws.lat32 is not None else ws.enc["x"][c["Ne"]]
         if self.has_le:
             ke = c["loss_e"]
@@ -1047,6 +1078,7 @@ class Engine:
         if dp is not None:
             dp.grads_ready(self.flat, "stem")
             dp.backward_done(self.flat)
+        trace.pop()
         if self.fp8:
             ws.fp8_complete = True
         # hand the gradient views to autograd's .grad slots (frozen and unused parameters keep None — encoder_norm: E1)

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import ops
+from . import ops, trace
 
 
 def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
@@ -96,6 +96,14 @@ class FusedAdamW(torch.optim.Optimizer):
         `flat.gate`, all-reduced with the gradients) the kernels return without touching weights, moments or the bf16 mirror — the
         reference raises before `backward` (engine_pretrain.py:56-58), this loop only notices at its next loss drain."""
         loss = closure() if closure is not None else None
+        trace.push("csmae.optimizer")
+        try:
+            self._step()
+        finally:
+            trace.pop()
+        return loss
+
+    def _step(self):
         flat = self._bind()
         g0 = flat.g.data_ptr()
         for gi, group in enumerate(self.param_groups):
@@ -116,9 +124,8 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp,
                       gate=flat.gate)
-            flat.raw_writes += 1   # the kernel wrote the masters (and the bf16 mirror) behind torch's version counters: the folded LayerNorm operands are stale
+            flat.raw_writes += 1   # the kernel wrote the masters (and the bf16 mirror) behind torch's version counters: mirrors derived from it (K-slab, fp8) are stale
             self._dirty_steps = True
-        return loss
 
     def _sync_steps(self):
         """torch's per-parameter `step` entries are refreshed lazily (state_dict / checkpointing), not 250 tensors per step."""

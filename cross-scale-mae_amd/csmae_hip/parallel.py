@@ -15,6 +15,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from . import trace
+
 
 def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized()
@@ -215,7 +217,8 @@ class DataParallel(torch.nn.Module):
             return
         sync = self._ensure(flat)
         if name in self._ranges:
-            sync.reduce_range(*self._ranges[name], also=also)
+            with trace.range_("csmae.exchange"):
+                sync.reduce_range(*self._ranges[name], also=also)
 
     def wants(self, name) -> bool:
         """True if `name` closes a bucket (lets the engine skip joining its weight-gradient stream otherwise)."""

@@ -60,3 +60,30 @@ extern "C" int csmae_stream_destroy(void* stream) {
 #define CSMAE_SRC_HASH "unknown"
 #endif
 extern "C" const char* csmae_source_hash(void) { return CSMAE_SRC_HASH; }   // sha256 of csrc/ at build time (tools/csrc_hash.py)
+
+// CSMAE_DEBUG="key[=value],..." lookup (common.h).  The returned pointer refers to a per-key copy that lives for the life of the process.
+#include <map>
+#include <mutex>
+#include <string>
+#include <cstring>
+#include <cstdlib>
+const char* csmae_debug_opt(const char* key) {
+  static std::mutex mu;
+  static std::map<std::string, std::string> found;
+  const char* env = getenv("CSMAE_DEBUG");
+  if (!env) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  const size_t kl = strlen(key);
+  for (const char* p = env; *p;) {
+    const char* e = strchr(p, ',');
+    const size_t len = e ? (size_t)(e - p) : strlen(p);
+    if (len >= kl && strncmp(p, key, kl) == 0 && (len == kl || p[kl] == '=')) {
+      std::string& v = found[key];
+      v = len == kl ? "1" : std::string(p + kl + 1, len - kl - 1);
+      return v.c_str();
+    }
+    if (!e) break;
+    p = e + 1;
+  }
+  return nullptr;
+}

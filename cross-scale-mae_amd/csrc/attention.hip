@@ -933,12 +933,12 @@ static void launch_fwd_bf16(int BH, const void* qkv, void* out, float* lse, int 
 template <int HD, int NKF>
 static void launch_bwd_bf16(int BH, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int T, int H, int D, int hd, float scale, hipStream_t st,
                             const Fp8Emit* em) {
-  static const bool two_pass = getenv("CSMAE_ATTN_BWD_2PASS") != nullptr;  // tuning aid: the older two-pass kernel
-  static const bool two_sweeps = getenv("CSMAE_ATTN_BWD_2SWEEP") != nullptr;  // tuning aid: one key pair per wave and sweep (the first single-pass version)
+  static const bool two_pass = csmae_debug_opt("attn_bwd_2pass") != nullptr;  // tuning aid: the older two-pass kernel
+  static const bool two_sweeps = csmae_debug_opt("attn_bwd_2sweep") != nullptr;  // tuning aid: one key pair per wave and sweep (the first single-pass version)
   constexpr bool KP2_OK = HD <= 32 && NKF >= 6 && NKF <= 16 && AttnBwd1p<HD, NKF>::LDS <= 160 * 1024;
   constexpr int NK1 = AttnBwd1p<HD, NKF>::LDS <= 160 * 1024 ? NKF : 2;
   constexpr bool W8_OK = NKF >= 18 && AttnBwd1p<HD, NKF>::LDS8 <= 160 * 1024;
-  static const bool four_waves = getenv("CSMAE_ATTN_BWD_4WAVES") != nullptr;   // tuning aid: the four-wave form for long sequences as well
+  static const bool four_waves = csmae_debug_opt("attn_bwd_4waves") != nullptr;   // tuning aid: the four-wave form for long sequences as well
 #define ATTN_BWD_ARGS (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, D, hd, scale
   if (KP2_OK && !two_pass && !two_sweeps) {
     if (em) CSMAE_LAUNCH((attn_bwd1p2_bf16<HD, (KP2_OK ? NKF : 2), true>), dim3(BH), dim3(256), 0, st, ATTN_BWD_ARGS, *em);

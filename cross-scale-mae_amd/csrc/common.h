@@ -29,6 +29,9 @@ __device__ __forceinline__ s8_t join_s4(s4_t lo, s4_t hi) {
   return __builtin_bit_cast(s8_t, make_uint4(l.x, l.y, h.x, h.y));
 }
 
+// ---- one gate for the settled A/B aids: CSMAE_DEBUG="key[=value],key,..." (the Python side reads the same variable: csmae_hip.debug_opt).
+// csmae_debug_opt returns the value of `key` ("1" for a bare key) or nullptr; host only, evaluated once per call site (static const).
+const char* csmae_debug_opt(const char* key);
 // ---- error plumbing (thread-local message; see include/csmae.h csmae_last_error)
 void csmae_set_error(const char* fmt, ...);
 int csmae_check_launch(const char* what);

@@ -870,7 +870,7 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
   p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
   p.dq_a = dq_a; p.dq_b = dq_b; p.a_fmt = a_fmt; p.aux_q8 = q8;
   if (c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll && (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) &&
-      ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) && !getenv("CSMAE_EPI_POINTERS"))
+      ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) && !csmae_debug_opt("epi_pointers"))
     p.a_fmt |= 256;   // buffer-addressed epilogue allowed (see gemm_core)
   p.q_out = reinterpret_cast<unsigned char*>(q_out); p.ldq = ldq; p.q_fmt = q_fmt; p.q_amax_prev = q_amax_prev; p.q_amax_next = q_amax_next; p.q_dq = q_dq;
   if (q_out) {   // (the fp8 copy leaves through the 16-byte-row epilogue only)
@@ -879,7 +879,7 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
                   "csmae_gemm_fp8: the fused fp8 copy needs a bf16 output with 8-element aligned rows and the three scale pointers");
   }
   dim3 grid(p.tiles_m * p.tiles_n);
-  static const bool two_stage_env = getenv("CSMAE_FP8_TWO_STAGE") != nullptr;   // A/B aid: the first (two-stage, barrier-per-step) kernel
+  static const bool two_stage_env = csmae_debug_opt("fp8_two_stage") != nullptr;   // A/B aid: the first (two-stage, barrier-per-step) kernel
   // the pipelined kernel fetches whole 128-byte K steps without predicates; a byte offset one tile past an operand's end must not wrap
   const bool two_stage = two_stage_env || K % 128 != 0 || (M + 256) * lda >= 0xFFFFFFF0ll || (N + 256) * ldb >= 0xFFFFFFF0ll;
   if (two_stage) {
@@ -948,15 +948,21 @@ extern "C" int csmae_gemm_force_tile(int cfg) { g_force_cfg = cfg; return 0; }
 // 0 never | 1 where a tile's time outside the MFMA loop is large — GELU / x gelu' epilogues, or K <= 512: the shapes it wins alone on the
 // chip (tools/k2_check.py) | 2 wherever it is eligible.  Defaults (measured in the step, gpurun_out/r05f): forward products 2 — beside the other
 // view's stream half-CU workgroups interleave better than whole-CU ones even where they lose alone (-0.4 ms per step) —, dX products 1 (2: +0.2 ms
-// beside the whole-CU weight-gradient launches).  csmae_gemm_k2_mode / CSMAE_K2_NN, CSMAE_K2_NT (A/B aids).
-static int k2_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int g_k2_nn = k2_env("CSMAE_K2_NN", 1);
-static int g_k2_nt = k2_env("CSMAE_K2_NT", 2);
+// beside the whole-CU weight-gradient launches).  csmae_gemm_k2_mode / CSMAE_K2 (A/B aids).
+// CSMAE_K2="nt,nn,dw" (e.g. "2,1,0", the defaults): which products run on the two-workgroups-per-CU kernels
+static int k2_env(int idx, int dflt) {
+  const char* e = getenv("CSMAE_K2");
+  int v[3] = {-1, -1, -1};
+  if (e) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+  return v[idx] >= 0 ? v[idx] : dflt;
+}
+static int g_k2_nn = k2_env(1, 1);
+static int g_k2_nt = k2_env(0, 2);
 // grouped weight-gradient launches: 0 = 256 x 256 tiles, one workgroup per CU (default) | 1 = 128 x 256 tiles, two per CU (k2_tile_tn).  Measured
 // (gpurun_out/r05k-m): alone on the chip 1 is 25 % faster at 128 slots (it spreads over all 256 CUs), 0-8 % slower at 160 / 256; in the step
 // +0.55 ms at the best slot setting (21.85 vs 21.30 ms): the main chain loses more to 12 DMA pieces per wave and K step on every CU than its
 // LayerNorm / attention kernels gain from finding half a CU free.  Kept as an option (csmae_gemm_dw_mode) with its tests.
-static int g_k2_dw = k2_env("CSMAE_K2_DW", 0);
+static int g_k2_dw = k2_env(2, 0);
 extern "C" int csmae_gemm_k2_mode(int nn, int nt) { g_k2_nn = nn; g_k2_nt = nt; return 0; }
 extern "C" int csmae_gemm_dw_mode(int k2) { g_k2_dw = k2; return 0; }
 int gemm_force_cfg() { return g_force_cfg; }
@@ -991,7 +997,7 @@ int gemm_core(int dtype, int transA, int transB, long long M, long long N, long 
   // whole, and a byte offset up to 256 rows past the end of any tensor the epilogue touches must not wrap (rows beyond M are range-checked away)
   if (dtype == CSMAE_BF16 && c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll &&
       (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) && ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) &&
-      !getenv("CSMAE_EPI_POINTERS"))   // (A/B aid: the pointer-addressed epilogues)
+      !csmae_debug_opt("epi_pointers"))   // (A/B aid: the pointer-addressed epilogues)
     p.a_fmt |= 256;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CSMAE_BF16) {
@@ -1155,7 +1161,7 @@ extern "C" int csmae_gemm_dw(int dtype, long long M, long long N, long long K, c
   const bool k64 = dtype == CSMAE_BF16 && tile == 256 && (g_force_cfg < 0 || (g_force_cfg & 7) == 4);  // same choice as csmae_gemm
   const int kt = dtype == CSMAE_BF16 ? (k64 ? 64 : GEMM_BK) : 16;
   const long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile), ktiles = cdiv(K, kt);
-  static const int slots256 = getenv("CSMAE_DW_SLOTS") ? atoi(getenv("CSMAE_DW_SLOTS")) : 160;  // blocks per weight-gradient GEMM (tuning aid): ~5/8 of the CUs — the rest runs the main stream — and fewer fp32 slabs than a full-chip split (flat optimum 128..192)
+  static const int slots256 = csmae_debug_opt("dw_slots") ? atoi(csmae_debug_opt("dw_slots")) : 160;  // blocks per weight-gradient GEMM (tuning aid): ~5/8 of the CUs — the rest runs the main stream — and fewer fp32 slabs than a full-chip split (flat optimum 128..192)
   const long long slots = dtype == CSMAE_BF16 ? (tile == 256 ? slots256 : 512) : 2048;
   long long S = slots / tiles;
   if (S > ktiles / (k64 ? 4 : 6)) S = ktiles / (k64 ? 4 : 6);

@@ -237,12 +237,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_k2_kernel(GemmArgs p) {
   }
   k2_tile<TB>(p, tm, tn);
 }
-// Clocks the second workgroup of a CU sleeps at the start of a launch (CSMAE_K2_STAGGER="a,b": a + b * K steps; default none).  Measured
+// Clocks the second workgroup of a CU sleeps at the start of a launch (CSMAE_DEBUG=k2_stagger=a:b: a + b * K steps clocks; default none).  Measured
 // (gpurun_out/r05d): with half a tile time of offset the delayed workgroup's loop runs at 2 100 instead of 2 480 clocks per K step, the launch
 // as a whole no faster — a workgroup alone on the matrix pipes is bound by its own DMA issue (12 pieces per wave and step), not by the pipe.
 static long long k2_stagger_sleeps(int nsteps, int epi) {
   static int a = -1, b = -1;
-  if (a < 0) { const char* e = getenv("CSMAE_K2_STAGGER"); if (!e || sscanf(e, "%d,%d", &a, &b) != 2) { a = 0; b = 0; } }
+  if (a < 0) { const char* e = csmae_debug_opt("k2_stagger"); if (!e || sscanf(e, "%d:%d", &a, &b) != 2) { a = 0; b = 0; } }
   if (a == 0 && b == 0) return 0;
   const long long clk = a + (long long)b * nsteps + ((epi == EPI_GELU || epi == EPI_DGELU) ? 4000 : 0);
   return clk / (127 * 64);
@@ -283,7 +283,7 @@ extern "C" int csmae_gemm_ks(int dtype, long long M, long long N, long long K, c
   p.ktiles = (int)(K / 64); p.ktiles_per_split = p.ktiles;
   p.tiles_m = cdiv(M, 128); p.tiles_n = cdiv(N, 256);
   if (c_dtype == CSMAE_BF16 && N % 8 == 0 && ldc % 8 == 0 && (M + 256) * ldc * 2 < 0xFFFFFFF0ll && (epilogue != EPI_RESID || (M + 256) * ldr * 2 < 0xFFFFFFF0ll) &&
-      ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) && !getenv("CSMAE_EPI_POINTERS"))
+      ((epilogue != EPI_GELU && epilogue != EPI_DGELU) || (M + 256) * ldaux * 2 < 0xFFFFFFF0ll) && !csmae_debug_opt("epi_pointers"))
     p.a_fmt |= 256;
   p.split_stride = k2_stagger_sleeps(p.ktiles, p.epi);
   CSMAE_LAUNCH((gemm_bf16_k2_kernel<false>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, (hipStream_t)stream, p);

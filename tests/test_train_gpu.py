@@ -423,7 +423,7 @@ def test_clip_grad_norm_with_user_frozen_parameters_stays_on_the_flat_buffer():
 def test_gradient_clear_on_the_side_stream_is_ordered_against_every_main_stream_writer(monkeypatch):
     """the flat gradient buffer is cleared on the weight-gradient stream while the reconstruction head's backward runs on the
     main stream; main-stream writers into the buffer wait for that clear through ONE event.  A writer placed above the wait would race it
-    and lose its contribution: the whole buffer must match the run whose clear sits on the main stream (CSMAE_ZERO_MAIN=1), step after
+    and lose its contribution: the whole buffer must match the run whose clear sits on the main stream (CSMAE_DEBUG=zero_main), step after
     step — bit for bit where the step is bit-reproducible at this geometry (checked first: two default runs), to rounding otherwise."""
     from csmae_hip.engine import FlatParams
     x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).cuda()
@@ -439,7 +439,7 @@ def test_gradient_clear_on_the_side_stream_is_ordered_against_every_main_stream_
             snaps.append(FlatParams.owner_of(m.decoder_pred.weight).g.clone())
         return snaps
     side, side2 = run(), run()
-    monkeypatch.setenv("CSMAE_ZERO_MAIN", "1")
+    monkeypatch.setenv("CSMAE_DEBUG", "zero_main")
     main = run()
     reproducible = all(torch.equal(a, b) for a, b in zip(side, side2))
     for a, b in zip(side, main):

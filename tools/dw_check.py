@@ -30,7 +30,7 @@ def run(items, slots, mode, ws, init=0.5):
 
 
 ws = torch.empty(128 << 20, device=dev)
-for K, prods, slots, pad in ((512, [(256, 256)], 4, 0), (1000, [(256, 512), (520, 264)], 16, 8), (4096, [(768, 768), (2304, 768)], 160, 0), (3000, [(512, 2048), (2048, 512)], 128, 0),
+for K, prods, slots, pad in ((12800, [(768, 3072), (3072, 768)], 256, 0), (512, [(256, 256)], 4, 0), (1000, [(256, 512), (520, 264)], 16, 8), (4096, [(768, 768), (2304, 768)], 160, 0), (3000, [(512, 2048), (2048, 512)], 128, 0),
                              (12800, [(768, 3072), (3072, 768)], 160, 0), (640, [(1024, 1024), (3072, 1024), (1024, 4096), (4096, 1024)], 256, 0)):
     items = group(K, prods, pad)
     o2, _ = run(items, slots, 1, ws)

@@ -11,8 +11,9 @@ from csmae_hip import ops
 L = csmae_hip.load()
 
 
-def run(label, K, prods, slots):
+def run(label, K, prods, slots, mode=0):
     dev = "cuda"
+    L.csmae_gemm_dw_mode(mode)
     ws = torch.empty(96 << 20, device=dev)
     items = []
     for M, N in prods:
@@ -30,17 +31,18 @@ def run(label, K, prods, slots):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
     buf = (ctypes.c_ulonglong * 8)()
-    L.csmae_debug_gemm_ts(buf)
+    (L.csmae_debug_k2_ts if mode else L.csmae_debug_gemm_ts)(buf)
     t = list(buf)
-    tiles = sum(-(-M // 256) * -(-N // 256) for M, N in prods)
-    S = max(1, min(slots // tiles, (K // 64) // 8))
+    tiles = sum(-(-M // (128 if mode else 256)) * -(-N // 256) for M, N in prods)
+    S = max(1, min((2 * slots if mode else slots) // tiles, (K // 64) // 8))
     kps = -(-(K // 64) // S)
     fl = sum(2.0 * M * N * K for M, N in prods)
-    print(f"{label:28s} slots {slots:3d}: {us:7.1f} us {fl / us / 1e6:7.1f} TF/s | tiles {tiles} x {S} slices of {kps} steps: pro {t[1] - t[0]:6d} loop {t[2] - t[1]:7d} = {(t[2] - t[1]) / kps:5.0f}/step epi {t[3] - t[2]:6d}")
+    print(f"{'k2 ' if mode else 'k64'} {label:28s} slots {slots:3d}: {us:7.1f} us {fl / us / 1e6:7.1f} TF/s | tiles {tiles} x {S} slices of {kps} steps: pro {t[1] - t[0]:6d} loop {t[2] - t[1]:7d} = {(t[2] - t[1]) / kps:5.0f}/step epi {t[3] - t[2]:6d}")
 
 
 for slots in (128, 160, 256):
-    run("dec fc2+fc1 (K=50432)", 50432, [(512, 2048), (2048, 512)], slots)
-    run("dec proj+qkv (K=50432)", 50432, [(512, 512), (1536, 512)], slots)
-    run("enc fc2+fc1 (K=12800)", 12800, [(768, 3072), (3072, 768)], slots)
-    run("enc proj+qkv (K=12800)", 12800, [(768, 768), (2304, 768)], slots)
+    for mode in (0, 1):
+        run("dec fc2+fc1 (K=50432)", 50432, [(512, 2048), (2048, 512)], slots, mode)
+        run("dec proj+qkv (K=50432)", 50432, [(512, 512), (1536, 512)], slots, mode)
+        run("enc fc2+fc1 (K=12800)", 12800, [(768, 3072), (3072, 768)], slots, mode)
+        run("enc proj+qkv (K=12800)", 12800, [(768, 768), (2304, 768)], slots, mode)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-stream timeline of one training step from a rocprofv3 rocpd DB: busy time per stream, idle gaps on the main stream,
-and a phase table (forward / backward / optimizer).  usage: step_timeline.py results.db [step_index]"""
+and a phase table.  With a DB taken with `--kernel-trace --marker-trace --hip-runtime-trace` the phases come from the roctx ranges the product
+emits (csmae_hip/trace.py: csmae.forward / csmae.backward.junction / .decoder / .encoder / csmae.optimizer / csmae.exchange): a kernel belongs to
+the innermost range its launch call was made in; without markers they are guessed from kernel names.  usage: step_timeline.py results.db [step_index]"""
 import sqlite3
 import sys
 
@@ -26,10 +28,47 @@ def main(db, step=-2):
     print(f" main-stream idle between kernels: {tot / 1e6:.3f} ms; gaps > 5 us: {len(gaps)}")
     for g, t, a, b in sorted(gaps, reverse=True)[:25]:
         print(f"   {g / 1e3:8.1f} us at {t:7.3f} ms  after {a}  before {b}")
+    if marker_phases(c, ks, s0):
+        return
     # phases: forward ends at the first kernel whose name contains 'bwd' or 'recon_bwd'
     tb = next((r[1] for r in ks if "bwd" in r[0]), s1)
     to = next((r[1] for r in ks if "adamw" in r[0]), s1)
     print(f" forward {(tb - s0) / 1e6:.3f} ms | backward {(to - tb) / 1e6:.3f} ms | optimizer+tail {(s1 - to) / 1e6:.3f} ms")
+
+
+def marker_phases(c, ks, s0):
+    """Phase table from roctx ranges; False when the DB holds none."""
+    try:
+        rng = c.execute("select name, start, end, id from regions where name like 'csmae.%' order by start").fetchall()
+        if not rng:   # some rocprofv3 builds name the region after the API call and keep the message as its argument
+            rng = c.execute("select a.arg_value, r.start, r.end, r.id from regions r join events_args a on a.event_id = r.event_id "
+                            "where a.arg_value like 'csmae.%' order by r.start").fetchall()
+        if not rng:
+            return False
+        ids = {r[0] for r in c.execute("select stack_id from kernels where start >= ? and start < ?", (ks[0][1], ks[-1][1] + 1))}
+        launches = dict(c.execute("select stack_id, start from regions where category like 'HIP%' and name like '%Launch%'").fetchall())
+        kmeta = c.execute("select name, start, end, stream_id, stack_id from kernels where start >= ? and start <= ? order by start", (ks[0][1], ks[-1][1])).fetchall()
+    except sqlite3.Error as e:
+        print(f" (marker phases unavailable: {e})")
+        return False
+    import bisect
+    starts = [r[1] for r in rng]
+    phases = {}
+    for name, st, en, sid, stack in kmeta:
+        t = launches.get(stack)
+        if t is None:
+            continue
+        # innermost range containing the launch call: the latest-starting range with start <= t < end
+        i = bisect.bisect_right(starts, t) - 1
+        while i >= 0 and not (rng[i][1] <= t < rng[i][2]):
+            i -= 1
+        ph = rng[i][0] if i >= 0 else "(outside any csmae range)"
+        d = phases.setdefault(ph, dict(n=0, busy=0, first=st, last=en))
+        d["n"] += 1; d["busy"] += en - st; d["first"] = min(d["first"], st); d["last"] = max(d["last"], en)
+    print(" phases from roctx ranges (kernels by the range their launch call was made in; GPU span = first kernel start .. last kernel end):")
+    for ph, d in sorted(phases.items(), key=lambda kv: kv[1]["first"]):
+        print(f"   {ph:34s} {d['n']:4d} kernels  GPU span {(d['first'] - s0) / 1e6:7.3f} .. {(d['last'] - s0) / 1e6:7.3f} ms ({(d['last'] - d['first']) / 1e6:6.3f} ms)  kernel time {d['busy'] / 1e6:7.3f} ms")
+    return True
 
 
 if __name__ == "__main__":
