@@ -221,7 +221,7 @@ def main():
     samples = torch.randn(a.batch, chans, size, size, device=device)
 
     if csmae_dbg("bench_stream"):   # experiment aid (CU partition): the whole step on a non-blocking stream of its own, nothing on
-        torch.cuda.set_stream(torch.cuda.Stream())   # the legacy null stream — a CU-masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags)
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1 if csmae_dbg("bench_stream") == "hi" else 0))   # the legacy null stream — a CU-masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags)
     main_cus = csmae_dbg("main_cus")   # ... "lo:hi" = mask bits of the main stream
     if main_cus:
         from csmae_hip import ops as _ops

@@ -266,6 +266,12 @@ class Engine:
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
+        for key in ("bwd_main_cus", "main_cus"):   # (a malformed experiment knob fails here, not in the middle of a backward pass)
+            v = debug_opt(key)
+            if v is not None and not (len(v.split(":")) == 2 and all(q.isdigit() for q in v.split(":")) and int(v.split(":")[0]) < int(v.split(":")[1])):
+                raise ValueError(f"CSMAE_DEBUG {key}={v!r}: expected lo:hi (mask bits of the compute units)")
+        if not str(debug_opt("dw_cus", "0")).isdigit():
+            raise ValueError(f"CSMAE_DEBUG dw_cus={debug_opt('dw_cus')!r}: expected the number of CUs per XCD")
         self.use_ks = not debug_opt("no_kslab")   # (CSMAE_DEBUG=no_kslab: forward products through csmae_gemm with the plain weight mirror; no K-slab mirror is kept)
         self._dw_slots = int(debug_opt("dw_slots", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —

@@ -67,12 +67,17 @@ def stream() -> int:
 _masked = {}
 
 
-def cu_masked_stream(lo: int, hi: int, total_cus: int = 256):
+def cu_masked_stream(lo: int, hi: int, total_cus: int = None):
     """A torch stream whose kernels run only on the compute units of mask bits [lo, hi) (csmae_stream_create_cu_mask: bit i is CU i / 8 of
     XCD i % 8, so a range whose ends are multiples of 8 is the same CUs in every XCD).  Cached per range: queues are a finite resource."""
+    if total_cus is None:
+        total_cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     key = (lo, hi, total_cus, torch.cuda.current_device())
     s = _masked.get(key)
     if s is None:
+        if not _masked:
+            import atexit
+            atexit.register(_destroy_masked)
         if not (0 <= lo < hi <= total_cus):
             raise ValueError(f"cu_masked_stream: empty or out-of-range CU range [{lo}, {hi}) of {total_cus}")
         words = (total_cus + 31) // 32
@@ -82,6 +87,15 @@ def cu_masked_stream(lo: int, hi: int, total_cus: int = 256):
         check(load().csmae_stream_create_cu_mask(words, ctypes.cast(mask, ctypes.c_void_p), ctypes.cast(ctypes.byref(h), ctypes.c_void_p)), "csmae_stream_create_cu_mask")
         s = _masked[key] = torch.cuda.ExternalStream(h.value)
     return s
+
+
+def _destroy_masked():
+    for s in _masked.values():
+        try:
+            load().csmae_stream_destroy(s.cuda_stream)
+        except Exception:
+            pass
+    _masked.clear()
 
 
 class launch_done:

@@ -41,7 +41,8 @@ class MAE_ViT_Shared(nn.Module):
 
     def random_masking(self, x, mask_ratio):
         """MAE_ViT_Shared.py:57-84.  Indices come from the HIP rank-sort (stable ascending == argsort on tie-free rows), the kept rows
-        from a HIP row gather (inside the step both are fused into patch_gather)."""
+        from a HIP row gather (inside the step both are fused into patch_gather).  The HIP gather is inference-only (no autograd node):
+        inputs that require grad go through torch.gather."""
         from csmae_hip import ops
         N, L, D = x.shape
         keep = int(L * (1 - mask_ratio))
@@ -52,6 +53,11 @@ class MAE_ViT_Shared(nn.Module):
         ops.mask_sort(noise, keep, ids_restore, mask, ids_keep)
         if keep < 1:
             return x.new_empty(N, 0, D), mask, ids_restore
+        if torch.is_grad_enabled() and x.requires_grad:
+            #  the HIP gather is a raw kernel outside autograd: a caller that differentiates through the masked tokens — as the
+            # reference's forward_encoder does — takes torch.gather with the same indices instead of silently losing the gradient
+            idx = ids_keep[:, :keep].long().unsqueeze(-1).expand(-1, -1, D)
+            return torch.gather(x, 1, idx), mask, ids_restore
         x32 = x.contiguous().float()
         x_masked = ops.rows_gather_idx(x32, ids_keep, keep, torch.empty(N, keep, D, device=x.device, dtype=torch.float32))
         return x_masked.to(x.dtype), mask, ids_restore

@@ -436,7 +436,9 @@ def test_gradient_clear_on_the_side_stream_is_ordered_against_every_main_stream_
             m._test_draws = _draws(k + 1)
             m.zero_grad(set_to_none=True)
             m(x)[0].backward()
-            snaps.append(FlatParams.owner_of(m.decoder_pred.weight).g.clone())
+            flat = FlatParams.owner_of(m.decoder_pred.weight)
+            snaps.append(flat.g.clone())
+        run.slots = dict(flat.slots)
         return snaps
     side, side2 = run(), run()
     monkeypatch.setenv("CSMAE_DEBUG", "zero_main")
@@ -446,8 +448,40 @@ def test_gradient_clear_on_the_side_stream_is_ordered_against_every_main_stream_
         if reproducible:
             assert torch.equal(a, b)
         else:   # (small shapes take kernels whose reduction order is not fixed: a lost contribution is orders of magnitude above that noise)
-            scale = float(b.abs().max())
-            assert float((a - b).abs().max()) <= 1e-3 * scale, (float((a - b).abs().max()), scale)
+            #  per parameter slot, against that slot's own magnitude: a lost write into a small-magnitude slot (BatchNorm / LayerNorm
+            # parameters, cls / mask tokens — the main- and auxiliary-stream writers this test is about) is far below 1e-3 of the GLOBAL maximum
+            for name, (o, n, _) in run.slots.items():
+                sa, sb = a[o:o + n], b[o:o + n]
+                scale = float(sb.abs().max())
+                assert float((sa - sb).abs().max()) <= 1e-3 * scale + 1e-12, (name, float((sa - sb).abs().max()), scale)
+
+
+def test_serial_heads_match_the_overlapped_junction(monkeypatch):
+    """the profiled / A-B path (CSMAE_DW_MAIN=1: every head on the main stream, the cross-decoder target gradient accumulated in
+    fp32 by pair_loss_bwd) and the shipped step (predictor backward on the auxiliary stream, the target gradient added from the bf16 `dv` by
+    rows_scatter_add2) compute the same gradients up to that one bf16 rounding of dv: every parameter slot within 2e-2 of its own maximum
+    (measured: <= 4e-3), the loss identical."""
+    from csmae_hip.engine import FlatParams
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run():
+        m = _cecd()
+        m.compute_dtype = torch.bfloat16
+        m._test_draws = _draws(7)
+        m.zero_grad(set_to_none=True)
+        loss = m(x)[0]
+        loss.backward()
+        flat = FlatParams.owner_of(m.decoder_pred.weight)
+        torch.cuda.synchronize()
+        return float(loss), flat.g[: flat.total].clone(), dict(flat.slots)
+    l0, g0, slots = run()
+    monkeypatch.setenv("CSMAE_DW_MAIN", "1")
+    l1, g1, _ = run()
+    assert l0 == l1
+    for name, (o, n, _) in slots.items():
+        a, b = g0[o:o + n], g1[o:o + n]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-2 * scale + 1e-12, (name, float((a - b).abs().max()), scale)
 
 
 def test_non_finite_loss_never_reaches_the_weights():
