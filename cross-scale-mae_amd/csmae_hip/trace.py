@@ -16,7 +16,7 @@ def _load():
     global _lib, _tried
     if not _tried:
         _tried = True
-        for name in ("libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"):
+        for name in ("librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"):   # (rocprofv3 intercepts the rocprofiler-sdk one)
             try:
                 lib = ctypes.CDLL(name)
                 lib.roctxRangePushA.argtypes = [ctypes.c_char_p]

@@ -15,9 +15,11 @@ sys.exit(0 if lib == src else f'libcsmae_hip.so was built from csrc {lib[:16]}, 
 timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
 python tools/rocpd_stats.py $(find /tmp/prof_$tag -name '*.db' | head -1) $out/step_kernel_stats.txt > /dev/null
-# per-stream timeline with the phases taken from the roctx ranges the product emits (csmae_hip/trace.py): kernel + marker + HIP-API trace of a short run
+python tools/step_timeline.py $(find /tmp/prof_$tag -name '*.db' | head -1) > $out/step_timeline.txt 2>&1
+# ... and the phases from the roctx ranges the product emits (csmae_hip/trace.py): kernel + marker + HIP-API trace of a short run (attribution only:
+# under API tracing the host falls behind the GPU, so that run's gaps are the profiler's)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace -d /tmp/profm_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing --steps 6 --warmup 2 > /dev/null 2>&1 )
-python tools/step_timeline.py $(find /tmp/profm_$tag -name '*.db' | head -1) > $out/step_timeline.txt 2>&1
+python tools/step_timeline.py $(find /tmp/profm_$tag -name '*.db' | head -1) --phases-only >> $out/step_timeline.txt 2>&1
 ( cd /tmp && CSMAE_DW_MAIN=1 CSMAE_FWD_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profs_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
 python tools/rocpd_stats.py $(find /tmp/profs_$tag -name '*.db' | head -1) $out/step_serialised_kernel_stats.txt > /dev/null
 bash tools/roofline_round.sh $tag > /dev/null 2>&1   # per-kernel HBM GB/s + MFMA utilisation (kernel_roofline.txt) and the HBM traffic table / pmc_traffic.json
