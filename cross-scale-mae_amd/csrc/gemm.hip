@@ -229,14 +229,18 @@ extern "C" int csmae_debug_gemm_ts(unsigned long long* out) { return (int)hipMem
 // Grouped weight-gradient launches (csmae_gemm_dw_group): where K slice `split` of tile `slot` parks its fp32 tile ([nsplit][nslots]
 // dense 256 x 256 slabs) and its column-sum partials ([nsplit][nslots][256]) when a tile is cut into several slices.
 struct DwFold { float* slab; float* cs_slab; int nsplit; int slot; int nslots; };
+#define K64_LDS_BYTES (5 * 256 * 64 * 2)   // ring of five 32-KiB units: all 160 KiB
 
-template <bool TA, bool TB, int BM, bool GROUP>
-__device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold fold) {
+// CSV: bias-gradient sums (K-strided-A products only) 0 = decided at run time (p.colsum && tn == 0) | 1 = never | 2 = always: the grouped weight-gradient
+// kernel branches ONCE per tile into instantiation 1 or 2, so that the loop of the tiles that do not sum (most) carries none of the 16 wave-uniform
+// branches per K step the run-time form costs it (35 of 231 instructions per wave and step).
+template <bool TA, bool TB, int BM, bool GROUP, int CSV = 0>
+__device__ __forceinline__ void k64_tile(char* smem, const GemmArgs& p, const int tm, const int tn, const int split, const int kt_begin, const int kt_end, const DwFold fold) {
   static_assert(BM == 256 || (BM == 192 && !TA), "192-row tiles exist for K-contiguous A only");
   constexpr int BN = 256, WM = BM / 2, WN = 64, NWN = BN / WN, NW = 8, FM = WM / 16, FN = WN / 16;
   constexpr int UNIT = 256 * 64 * 2, NUNIT = 5, PPU = UNIT / 1024 / NW;  // ring slot = 32 KiB; a B image fills it, a 192-row A image uses 24 KiB
   constexpr int PPA = BM * 64 * 2 / 1024 / NW;                            // DMA pieces per wave of an A image (4 or 3)
-  __shared__ __attribute__((aligned(16))) char smem[NUNIT * UNIT];
+  static_assert(NUNIT * UNIT == K64_LDS_BYTES, "LDS of the pipelined kernels");
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = lane & 15, g = lane >> 4;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -355,7 +359,7 @@ __device__ __forceinline__ void k64_tile(const GemmArgs& p, const int tm, const 
   // bias gradient (sum_k A(m,k), weight-gradient products only) on the VALU slots the MFMAs leave free: on the tn == 0 tiles wave
   // (wm, wq) sums fragments 2wq and 2wq+1, which its three wn-neighbours hold as well.  The branch is wave-uniform and contains
   // no memory operation, so it does not disturb the counters of the pipelined loop.
-  const bool do_cs = TA && TB && p.colsum != nullptr && tn == 0;
+  const bool do_cs = TA && TB && (CSV == 2 || (CSV == 0 && p.colsum != nullptr && tn == 0));
   const int wq = w % NWN;
   float cs[2] = {0.f, 0.f};
   auto mma_row = [&](int i, const s8_t& fa, const s8_t (&fb)[FN]) {
@@ -540,7 +544,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_k64_kernel(GemmArgs p) {  //
   const int kt_begin = split * p.ktiles_per_split;
   const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles);
   if (kt_begin >= kt_end) return;  // only possible for surplus split-K slices
-  k64_tile<TA, TB, BM, false>(p, tm, tn, split, kt_begin, kt_end, DwFold{});
+  __shared__ __attribute__((aligned(16))) char smem[K64_LDS_BYTES];
+  k64_tile<TA, TB, BM, false>(smem, p, tm, tn, split, kt_begin, kt_end, DwFold{});
 }
 // ---- grouped weight gradients: the dW products of a transformer block (qkv, proj, fc1, fc2 — same token axis K) in ONE launch.
 // A product on its own cannot fill the chip without cutting K into 10 .. 60 slices (768 x 768: 9 tiles), each of which pays a 256-KiB
@@ -564,7 +569,10 @@ __global__ __launch_bounds__(512, 1) void gemm_dw_group_kernel(DwGroupArgs ga) {
   p.c_dtype = CSMAE_F32; p.epi = EPI_RESID; p.splitk = ga.nsplit; p.tiles_m = 0; p.tiles_n = d.tiles_n; p.ktiles = ga.ktiles; p.ktiles_per_split = ga.ktiles_per_split;
   p.a_bytes = (unsigned)((long long)ga.K * d.ldy * 2); p.b_bytes = (unsigned)((long long)ga.K * d.ldx * 2);
   p.force_cfg = ga.force_cfg; p.split_stride = 0; p.colsum = d.db; p.dq_a = p.dq_b = nullptr; p.a_fmt = 0; p.aux_q8 = 0; p.q_out = nullptr;
-  k64_tile<true, true, 256, true>(p, tm, tn, split, kt_begin, kt_end, DwFold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles});
+  __shared__ __attribute__((aligned(16))) char smem[K64_LDS_BYTES];
+  const DwFold fold{ga.slab, ga.cs_slab, ga.nsplit, tile_id, ga.total_tiles};
+  if (d.db != nullptr && tn == 0) k64_tile<true, true, 256, true, 2>(smem, p, tm, tn, split, kt_begin, kt_end, fold);
+  else k64_tile<true, true, 256, true, 1>(smem, p, tm, tn, split, kt_begin, kt_end, fold);
 }
 // fold of the K slices of a grouped launch: workgroup (tile, part) adds the tile's slabs in slice order and accumulates 16 rows into
 // dW (16-byte accesses along rows); part 0 of the tn == 0 tiles does the same for the bias gradient.  Ordered: bit-reproducible.
