@@ -448,11 +448,11 @@ def loss_finalize(per_view, views, rowloss, mask, recon_scale, losses, cd_partia
                                      _p(ce_rowloss), ce_rows, _p(losses), st if st is not None else stream()), "csmae_loss_finalize")
 
 
-def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps, step, p_lp=None, gate=None, st=None):
+def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps, step, p_lp=None, gate=None, tile_ks=None, p_ks=None, st=None):
     """One fused AdamW step over the tiles; `step` (1-based) sets the bias corrections 1 - beta^step; a non-finite `gate` (device
-    scalar) turns the launch into a no-op."""
+    scalar) turns the launch into a no-op.  tile_ks (int64 [ntiles, 3]: weight offset, N, K; K = 0 none) + p_ks: also write the K-slab mirrors."""
     check(load().csmae_adamw(tile_off.numel(), _p(tile_off), _p(tile_cnt), _p(tile_wd), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1),
-                             float(beta2), float(eps), 1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(p_lp), _p(gate),
+                             float(beta2), float(eps), 1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(p_lp), _p(gate), _p(tile_ks), _p(p_ks),
                              st if st is not None else stream()), "csmae_adamw")
 
 

@@ -62,19 +62,26 @@ class FusedAdamW(torch.optim.Optimizer):
             self._sync_steps()
             for old in [k for k in self._plans if k[0] == gi]:  # the group's active set changed: its old plan (and counter) is superseded
                 del self._plans[old]
-            offs, cnts, params = [], [], []
+            offs, cnts, params, ks = [], [], [], []
+            ks_names = getattr(flat, "ks_names", None) if getattr(flat, "w_ks", None) is not None else None
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 params.append(p)
-                off, n, _ = flat.slot_of(p)
+                off, n, shape = flat.slot_of(p)
+                # the K-slab mirror of a block Linear weight (Engine._refresh_ks) is written by the same launch: (weight offset, N, K) per tile
+                row = (off, shape[0], shape[1]) if (ks_names is not None and flat._by_id[id(p)] in ks_names) else (0, 0, 0)
                 for o in range(0, n, self.TILE):
                     offs.append(off + o)
                     cnts.append(min(self.TILE, n - o))
+                    ks.append(row)
             dev = flat.p.device
             wd = float(group["weight_decay"])
+            has_ks = any(r[2] for r in ks)
             self._plans[key] = dict(off=torch.tensor(offs, dtype=torch.long, device=dev), cnt=torch.tensor(cnts, dtype=torch.int32, device=dev),
                                     wd=torch.full((len(offs),), wd, device=dev), wd_host=wd, params=params,
+                                    ks=torch.tensor(ks, dtype=torch.long, device=dev).reshape(-1, 3) if has_ks else None,
+                                    ks_names={flat._by_id[id(q)] for q in params} & set(ks_names) if has_ks else set(),
                                     step=self._common_step(params))
         return self._plans[key]
 
@@ -106,6 +113,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def _step(self):
         flat = self._bind()
         g0 = flat.g.data_ptr()
+        ks_before = getattr(flat, "ks_stamp", None) is not None and flat.ks_stamp == (flat.lp_stamp, flat.raw_writes)   # K-slab mirror consistent on entry
+        ks_written = set()
         for gi, group in enumerate(self.param_groups):
             plan = self._plan(gi, group, flat)
             params = plan["params"]
@@ -122,10 +131,17 @@ class FusedAdamW(torch.optim.Optimizer):
                 plan["wd"].fill_(wd)
                 plan["wd_host"] = wd
             b1, b2 = group["betas"]
+            ks_ok = plan["ks"] is not None and flat.w_lp is not None and getattr(flat, "w_ks", None) is not None
             ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp,
-                      gate=flat.gate)
-            flat.raw_writes += 1   # the kernel wrote the masters (and the bf16 mirror) behind torch's version counters: mirrors derived from it (K-slab, fp8) are stale
+                      gate=flat.gate, tile_ks=plan["ks"] if ks_ok else None, p_ks=flat.w_ks if ks_ok else None)
+            # the kernel wrote the masters (and the bf16 mirror) behind torch's version counters: mirrors derived from it (fp8) are stale.  The K-slab
+            # mirror is not, when this launch wrote it for every weight that has one and it was consistent before (Engine._refresh_ks's stamp)
+            flat.raw_writes += 1
+            if ks_ok:
+                ks_written |= plan["ks_names"]
             self._dirty_steps = True
+        if ks_before and ks_written and ks_written == set(flat.ks_names):   # every K-slab mirror was re-written by the launches above: still consistent
+            flat.ks_stamp = (flat.lp_stamp, flat.raw_writes)
 
     def _sync_steps(self):
         """torch's per-parameter `step` entries are refreshed lazily (state_dict / checkpointing), not 250 tensors per step."""

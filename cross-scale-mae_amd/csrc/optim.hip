@@ -11,7 +11,8 @@
 __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict__ tile_off, const int* __restrict__ tile_cnt,
                                                     const float* __restrict__ tile_wd, float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2, float eps,
-                                                    float bc1, float bc2, bf16_t* __restrict__ p_lp, const float* __restrict__ gate) {
+                                                    float bc1, float bc2, bf16_t* __restrict__ p_lp, const float* __restrict__ gate,
+                                                    const long long* __restrict__ tile_ks, bf16_t* __restrict__ p_ks) {
   // update gate (device scalar, nullable): the step's loss, summed over micro-steps and averaged over ranks with the gradients (it
   // rides in the tail slot of the flat gradient buffer).  A non-finite value means non-finite gradients on every rank: the update
   // is skipped as a whole — weights, moments and the bf16 mirror stay as they are — and the host raises at its next loss drain.
@@ -20,6 +21,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict_
   const int cnt = tile_cnt[blockIdx.x];
   const float wd = tile_wd[blockIdx.x];
   const float step_size = lr / bc1, rbc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+  // K-slab mirror (csmae.h csmae_gemm_ks) of a block Linear weight [N][K], written here instead of by a csmae_weights_kslab launch per step:
+  // tile_ks[tile] = {flat offset of the weight's first element, N, K} (K = 0: this tile's parameter has none).  K % 32 == 0 and slots are
+  // 8-aligned, so the 4 consecutive elements a thread owns stay inside one 32-wide K group: one 8-byte store.
+  long long wbase = 0; int ksN = 0, ksK = 0;
+  if (tile_ks != nullptr && p_ks != nullptr) { wbase = tile_ks[blockIdx.x * 3]; ksN = (int)tile_ks[blockIdx.x * 3 + 1]; ksK = (int)tile_ks[blockIdx.x * 3 + 2]; }
   for (int i = threadIdx.x * 4; i < cnt; i += blockDim.x * 4) {
     if (i + 4 <= cnt && ((off + i) & 3) == 0) {
       f4_t pp = *reinterpret_cast<f4_t*>(p + off + i), gg = *reinterpret_cast<const f4_t*>(g + off + i);
@@ -33,6 +39,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict_
       }
       *reinterpret_cast<f4_t*>(p + off + i) = pp; *reinterpret_cast<f4_t*>(m + off + i) = mm; *reinterpret_cast<f4_t*>(v + off + i) = vv;
       if (p_lp) st4<bf16_t>(p_lp + off + i, pp);
+      if (ksK) {
+        const int e = (int)(off + i - wbase), n = e / ksK, k = e - n * ksK;
+        st4<bf16_t>(p_ks + wbase + ((long long)(k >> 5) * ksN + n) * 32 + (k & 31), pp);
+      }
     } else {
       for (int k = i; k < cnt && k < i + 4; ++k) {
         float pp = p[off + k] * decay, gg = g[off + k];
@@ -41,17 +51,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict_
         pp -= step_size * (mm / (sqrtf(vv) * rbc2 + eps));
         p[off + k] = pp; m[off + k] = mm; v[off + k] = vv;
         if (p_lp) p_lp[off + k] = f2bf(pp);
+        if (ksK) {
+          const int e = (int)(off + k - wbase), n = e / ksK, kk = e - n * ksK;
+          p_ks[wbase + ((long long)(kk >> 5) * ksN + n) * 32 + (kk & 31)] = f2bf(pp);
+        }
       }
     }
   }
 }
 extern "C" int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
                            float* m, float* v, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
-                           void* p_lp, const float* gate, void* stream) {
+                           void* p_lp, const float* gate, const long long* tile_ks, void* p_ks, void* stream) {
   CSMAE_REQUIRE(ntiles > 0 && tile_off && tile_cnt && tile_wd && p && g && m && v, "csmae_adamw: null argument");
   CSMAE_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, "csmae_adamw: bias corrections must be positive (step >= 1)");
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps,
-                     bias_correction1, bias_correction2, (bf16_t*)p_lp, gate);
+                     bias_correction1, bias_correction2, (bf16_t*)p_lp, gate, tile_ks, (bf16_t*)p_ks);
   return csmae_check_launch("csmae_adamw");
 }
 

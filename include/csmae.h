@@ -235,9 +235,11 @@ int csmae_augment_u8(long long N, int C, int Hmax, int Wmax, int S, const unsign
 /* ---- optimizer side (main_pretrain.py:426-427 torch.optim.AdamW; util/misc.py:314 backward products) */
 /* gate (nullable device scalar): the update is skipped as a whole when it is not finite — engine_pretrain.py:56-58 raises on a
  * non-finite loss BEFORE backward / step; here the loss stays on the device and the kernel keeps the poisoned step out of the weights. */
+/* tile_ks / p_ks (nullable, ABI 6): the launch also writes the K-slab mirrors (csmae_gemm_ks) of the weights it steps — tile_ks[tile] =
+ * {flat offset of the tile's weight, N, K} (device int64 [ntiles][3]; K = 0: none) — so that no csmae_weights_kslab launch is needed per step. */
 int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
                 float* m, float* v, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
-                void* p_lp, const float* gate, void* stream);
+                void* p_lp, const float* gate, const long long* tile_ks, void* p_ks, void* stream);
 int csmae_gate_accumulate(const float* loss, float* slot, int accumulate, void* stream);
 /* util/misc.py:310-318 (`torch.nn.utils.clip_grad_norm_(parameters, clip_grad)`) / :338-355 (`get_grad_norm_`) on the flat gradient
  * buffer: out[0] = total 2-norm, out[1] = min(1, max_norm / (norm + 1e-6)); g *= out[1] in place when max_norm > 0 (<= 0: norm only).
