@@ -45,9 +45,15 @@ def marker_phases(c, ks, s0):
     """Phase table from roctx ranges; False when the DB holds none."""
     try:
         rng = c.execute("select name, start, end, id from regions where name like 'csmae.%' order by start").fetchall()
-        if not rng:   # some rocprofv3 builds name the region after the API call and keep the message as its argument
-            rng = c.execute("select a.arg_value, r.start, r.end, r.id from regions r join events_args a on a.event_id = r.event_id "
-                            "where a.arg_value like 'csmae.%' order by r.start").fetchall()
+        if not rng:   # rocprofv3 (ROCm 7): the region is named after the API call (roctxThreadRangeA), the message sits in extdata: {"message": "csmae.forward"}
+            import json
+            for ext, st, en, rid in c.execute("select extdata, start, end, id from regions where category like 'MARKER%' order by start").fetchall():
+                try:
+                    msg = json.loads(ext).get("message", "")
+                except (ValueError, TypeError):
+                    msg = ""
+                if msg.startswith("csmae."):
+                    rng.append((msg, st, en, rid))
         if not rng:
             return False
         ids = {r[0] for r in c.execute("select stack_id from kernels where start >= ? and start < ?", (ks[0][1], ks[-1][1] + 1))}
