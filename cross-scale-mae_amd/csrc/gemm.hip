@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 static int g_force_cfg = -1;  // tuning hook (tools/gemm_bench.py): -1 = heuristic
 extern "C" int csmae_gemm_force_tile(int cfg) { g_force_cfg = cfg; return 0; }
 // Which products run on the two-workgroups-per-CU kernel (gemm_k2.hip), per use (nn: dX through csmae_gemm, nt: csmae_gemm_ks):
-// 0 never | 1 where a tile's time outside the MFMA loop is large — GELU / x gelu' epilogues, or K <= 512: the shapes it wins alone on the
+// 0 never | 3 wherever eligible, whatever the size (tools) | 1 where a tile's time outside the MFMA loop is large — GELU / x gelu' epilogues, or K <= 512: the shapes it wins alone on the
 // chip (tools/k2_check.py) | 2 wherever it is eligible.  Defaults (measured in the step, gpurun_out/r05f): forward products 2 — beside the other
 // view's stream half-CU workgroups interleave better than whole-CU ones even where they lose alone (-0.4 ms per step) —, dX products 1 (2: +0.2 ms
 // beside the whole-CU weight-gradient launches).  csmae_gemm_k2_mode / CSMAE_K2 (A/B aids).
@@ -974,15 +974,21 @@ static int g_k2_dw = k2_env(2, 0);
 extern "C" int csmae_gemm_k2_mode(int nn, int nt) { g_k2_nn = nn; g_k2_nt = nt; return 0; }
 extern "C" int csmae_gemm_dw_mode(int k2) { g_k2_dw = k2; return 0; }
 int gemm_force_cfg() { return g_force_cfg; }
-static bool k2_wanted(int mode, int epilogue, long long K, long long N) {
+static bool k2_wanted(int mode, int epilogue, long long K, long long N, long long M) {
+  // size bounds (all modes but 3 = force): the kernel stages 1.5x the bytes of the 256 x 256 tile, which a weight that fits an XCD's L2 hides and a
+  // larger one does not (ViT-H/14: every product on it +5.6 % per step, gpurun_out/r05z) — weight elements N x K and launch rows M
+  static const long long wmax = csmae_debug_opt("k2_wmax") ? atoll(csmae_debug_opt("k2_wmax")) : 2400000ll;
+  static const long long mmax = csmae_debug_opt("k2_mmax") ? atoll(csmae_debug_opt("k2_mmax")) : (1ll << 40);
+  if (mode == 3) return true;
+  if (N * K > wmax || M > mmax) return false;
   // beyond K = 512: products up to K = 1 536 with N <= 512 (ViT-B: the decoder's qkv-dX) — 21.39 against 21.50 ms over three interleaved rounds
   // (gpurun_out/r05y; K <= 2 048 / N <= 512: 21.45, K <= 768 / N <= 768: 21.45).  CSMAE_DEBUG=k2_kmax=..,k2_nmax=.. re-opens the question.
   static const int kmax = csmae_debug_opt("k2_kmax") ? atoi(csmae_debug_opt("k2_kmax")) : 1536;
   static const int nmax = csmae_debug_opt("k2_nmax") ? atoi(csmae_debug_opt("k2_nmax")) : 512;
   return mode >= 2 || (mode == 1 && (epilogue == EPI_GELU || epilogue == EPI_DGELU || K <= 512 || (K <= kmax && N <= nmax)));
 }
-bool gemm_k2_nn_wanted(int epilogue, long long K, long long N) { return k2_wanted(g_k2_nn, epilogue, K, N); }
-bool gemm_k2_nt_wanted(int epilogue, long long K, long long N) { return k2_wanted(g_k2_nt, epilogue, K, N); }
+bool gemm_k2_nn_wanted(int epilogue, long long K, long long N, long long M) { return k2_wanted(g_k2_nn, epilogue, K, N, M); }
+bool gemm_k2_nt_wanted(int epilogue, long long K, long long N, long long M) { return k2_wanted(g_k2_nt, epilogue, K, N, M); }
 
 int gemm_core(int dtype, int transA, int transB, long long M, long long N, long long K,
                      const void* A, long long lda, const void* B, long long ldb,
@@ -1039,7 +1045,7 @@ int gemm_core(int dtype, int transA, int transB, long long M, long long N, long 
     int stg = 4;
     // 6: 128 x 256 tiles, two 4-wave workgroups per CU (k2_tile): K-contiguous A, K-strided B (dX products), whole 64-wide K steps
     const bool k2_ok = !transA && transB && splitk == 1 && K % 64 == 0 && M >= 128 && N >= 256 && (M + 128) * lda * 2 < 0xFFFFFFF0ll && (K + 64) * ldb * 2 < 0xFFFFFFF0ll;
-    if (cfg >= 4 && k2_ok && gemm_k2_nn_wanted(epilogue, K, N)) cfg = 6;
+    if (cfg >= 4 && k2_ok && gemm_k2_nn_wanted(epilogue, K, N, M)) cfg = 6;
     if (p.force_cfg >= 0) cfg = p.force_cfg & 7; else p.force_cfg = 0;
     if (cfg == 6 && !k2_ok) cfg = 4;
     if (cfg > 6) cfg = 4;

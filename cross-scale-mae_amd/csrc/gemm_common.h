@@ -517,8 +517,8 @@ struct DwGroupArgs {
 int gemm_k2_launch_dw(DwGroupArgs& ga, int count, int slots, float* workspace, long long ws_elems, hipStream_t st);   // gemm_k2.hip: 128 x 256 tiles, two workgroups per CU
 // host-side hooks shared by the two translation units
 int gemm_force_cfg();                 // csmae_gemm_force_tile's value (-1 = heuristic)
-bool gemm_k2_nn_wanted(int epilogue, long long K, long long N);   // policy of csmae_gemm_k2_mode (gemm.hip)
-bool gemm_k2_nt_wanted(int epilogue, long long K, long long N);
+bool gemm_k2_nn_wanted(int epilogue, long long K, long long N, long long M);   // policy of csmae_gemm_k2_mode (gemm.hip)
+bool gemm_k2_nt_wanted(int epilogue, long long K, long long N, long long M);
 int gemm_k2_launch_nn(const GemmArgs& p, hipStream_t st);   // gemm_bf16_k2_kernel<true> (gemm_k2.hip)
 int gemm_core(int dtype, int transA, int transB, long long M, long long N, long long K, const void* A, long long lda, const void* B, long long ldb,
               void* C, long long ldc, int c_dtype, const float* bias, int epilogue, void* aux, long long ldaux, const void* resid, long long ldr,

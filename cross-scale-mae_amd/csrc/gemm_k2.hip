@@ -261,7 +261,7 @@ extern "C" int csmae_gemm_ks(int dtype, long long M, long long N, long long K, c
                              const void* B_plain, long long ldb_plain, void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
                              void* aux, long long ldaux, const void* resid, long long ldr, void* stream) {
   const int epi_kind = epilogue == 6 ? EPI_GELU : (epilogue == 7 ? EPI_DGELU : epilogue);
-  const bool ok = dtype == CSMAE_BF16 && Bk && gemm_k2_nt_wanted(epi_kind, K, N) && (gemm_force_cfg() < 0 || (gemm_force_cfg() & 7) == 6) && K % 64 == 0 && M >= 128 && N >= 256 && N % 4 == 0 && ldc % 4 == 0 &&
+  const bool ok = dtype == CSMAE_BF16 && Bk && gemm_k2_nt_wanted(epi_kind, K, N, M) && (gemm_force_cfg() < 0 || (gemm_force_cfg() & 7) == 6) && K % 64 == 0 && M >= 128 && N >= 256 && N % 4 == 0 && ldc % 4 == 0 &&
                   lda % 8 == 0 && slab_rows >= N && (M + 128) * lda * 2 < 0xFFFFFFF0ll && (K / 32) * slab_rows * 64 < 0xFFFFFFF0ll &&
                   (((uintptr_t)A | (uintptr_t)Bk | (uintptr_t)C) & 15) == 0;
   if (!ok) {

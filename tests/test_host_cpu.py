@@ -270,3 +270,21 @@ def test_flat_params_version_stamp_sees_parameter_writes():
     flat.lp_stamp = flat.version_stamp()
     flat.mark_changed()
     assert flat.lp_stamp is None
+
+
+def test_debug_gate_and_trace_are_inert_by_default(monkeypatch):
+    """CSMAE_DEBUG="key[=value],..." is the one gate for settled A/B aids (csmae_hip.debug_opt); the roctx ranges of csmae_hip.trace are no-ops
+    without a profiler and must nest / unwind on exceptions."""
+    import csmae_hip
+    from csmae_hip import trace
+    monkeypatch.delenv("CSMAE_DEBUG", raising=False)
+    assert csmae_hip.debug_opt("zero_main") is None and csmae_hip.debug_opt("dw_slots", "160") == "160"
+    monkeypatch.setenv("CSMAE_DEBUG", "zero_main,dw_slots=96, bwd_main_cus=0:128")
+    assert csmae_hip.debug_opt("zero_main") == "1" and csmae_hip.debug_opt("dw_slots") == "96" and csmae_hip.debug_opt("bwd_main_cus") == "0:128"
+    assert csmae_hip.debug_opt("zero") is None      # keys match whole, not by prefix
+    with trace.range_("csmae.test"):
+        with trace.range_("csmae.test.inner"):
+            pass
+    with pytest.raises(RuntimeError):
+        with trace.range_("csmae.test"):
+            raise RuntimeError("unwinds")

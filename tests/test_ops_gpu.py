@@ -591,7 +591,7 @@ def test_gemm_two_workgroups_per_cu_kernel_is_bit_identical(ops, mnk):
         for epi, odt in ((EPI_NONE, torch.bfloat16), (EPI_NONE, torch.float32), (EPI_RESID, torch.bfloat16), (EPI_GELU, torch.bfloat16), (EPI_DGELU, torch.bfloat16)):
             for layout in ("nt", "nn"):
                 outs = []
-                for mode in (2, 0):
+                for mode in (3, 0):
                     lib.csmae_gemm_k2_mode(mode, mode)
                     out = torch.full((M, N), float("nan"), device="cuda", dtype=odt)
                     aux = codes.clone() if epi == EPI_DGELU else (torch.zeros(M, N, device="cuda", dtype=torch.uint8) if epi == EPI_GELU else None)
@@ -1141,6 +1141,39 @@ def test_adamw_matches_torch(ops):
         for i, p in enumerate(tp):
             assert_close(gp[offs[i]:offs[i] + sizes[i]], p, 1e-6, 1e-7, f"adamw step {step} tensor {i}")
     assert_close(lp[:1000], gp[:1000], 1e-2, 1e-3, "bf16 mirror")
+
+
+def test_adamw_writes_the_kslab_mirrors(ops):
+    """csmae_adamw with tile_ks / p_ks: the launch that steps the fp32 masters and the bf16 mirror also writes the K-slab mirror Wk[K/32][N][32] of the
+    weights that have one (csmae.h csmae_gemm_ks) — byte for byte what csmae_weights_kslab makes of the bf16 mirror afterwards; tiles of tensors
+    without a mirror (K = 0 rows) leave theirs untouched."""
+    shapes = [(256, 128), (37,), (520, 192), (64, 64)]          # [N, K] weights with K % 32 == 0, a bias, a weight WITHOUT a mirror
+    has_ks = [True, False, True, False]
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    offs = np.cumsum([0] + [(n + 7) // 8 * 8 for n in sizes])
+    total = int(offs[-1])
+    p = torch.zeros(total)
+    for i, n in enumerate(sizes):
+        p[offs[i]:offs[i] + n] = rnd(n, seed=400 + i)
+    g = rnd(total, seed=410)
+    toff, tcnt, tks = [], [], []
+    for i, n in enumerate(sizes):
+        for o in range(0, n, 4096):
+            toff.append(offs[i] + o); tcnt.append(min(4096, n - o))
+            tks.append((offs[i], shapes[i][0], shapes[i][1]) if has_ks[i] else (0, 0, 0))
+    toff, tcnt = torch.tensor(toff, device="cuda"), torch.tensor(tcnt, dtype=torch.int32, device="cuda")
+    twd = torch.full((len(tks),), 0.05, device="cuda")
+    tks = torch.tensor(tks, dtype=torch.long, device="cuda")
+    gp, gg = p.cuda(), g.cuda()
+    m, v = torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda")
+    lp = torch.zeros(total, device="cuda", dtype=torch.bfloat16)
+    ks = torch.full((total,), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.adamw(toff, tcnt, twd, gp, gg, m, v, 1e-2, 0.9, 0.95, 1e-8, 1, p_lp=lp, tile_ks=tks, p_ks=ks)
+    desc = torch.tensor([[offs[i], shapes[i][0], shapes[i][1]] for i in range(len(shapes)) if has_ks[i]], dtype=torch.long, device="cuda")
+    ref = torch.full((total,), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.weights_kslab(desc, lp, ref)
+    assert torch.equal(ks.view(torch.int16), ref.view(torch.int16))
+    assert float((lp[offs[0]:offs[0] + sizes[0]].float() - gp[offs[0]:offs[0] + sizes[0]]).abs().max()) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

@@ -57,16 +57,16 @@ def main():
             C1 = torch.empty_like(C2)
             if lay == "NT":
                 Wk = kslab(W)
-                lib.csmae_gemm_k2_mode(2, 2)
+                lib.csmae_gemm_k2_mode(3, 3)
                 ops.gemm_ks(A, Wk, W, C2, bias=bias)
                 ops.gemm(A, W, C1, bias=bias)
             else:
                 Wt = W.t().contiguous()   # [K][N]
-                lib.csmae_gemm_k2_mode(2, 2)
+                lib.csmae_gemm_k2_mode(3, 3)
                 ops.gemm(A, Wt, C2, trans_b=True, bias=bias)
                 lib.csmae_gemm_k2_mode(0, 0)
                 ops.gemm(A, Wt, C1, trans_b=True, bias=bias)
-                lib.csmae_gemm_k2_mode(2, 2)
+                lib.csmae_gemm_k2_mode(3, 3)
             torch.cuda.synchronize()
             err = (C2.float() - ref).abs().max().item() / ref.abs().max().item()
             same = torch.equal(C1, C2)
@@ -94,7 +94,7 @@ def main():
             Wk = kslab(W)
             f1 = lambda: ops.gemm(A, W, C1, bias=bias, epilogue=epi, aux=aux1, resid=resid)
             f2 = lambda: ops.gemm_ks(A, Wk, W, C2, bias=bias, epilogue=epi, aux=aux2, resid=resid)
-            lib.csmae_gemm_k2_mode(2, 2)
+            lib.csmae_gemm_k2_mode(3, 3)
             t1, t2 = timed(f1, a.iters), timed(f2, a.iters)
         else:
             Wt = W.t().contiguous()
@@ -102,7 +102,7 @@ def main():
             f2 = lambda: ops.gemm(A, Wt, C2, trans_b=True, bias=bias, epilogue=epi, aux=aux2, resid=resid)
             lib.csmae_gemm_k2_mode(0, 0)
             t1 = timed(f1, a.iters)
-            lib.csmae_gemm_k2_mode(2, 2)
+            lib.csmae_gemm_k2_mode(3, 3)
             t2 = timed(f2, a.iters)
         torch.cuda.synchronize()
         same = torch.equal(C1, C2) and (aux1 is None or torch.equal(aux1, aux2))

@@ -48,7 +48,7 @@ for label, M, N, K, epi in (("dec.qkv", 50432, 1536, 512, 0), ("dec.fc1+gelu", 5
     resid = torch.randn(M, N, device="cuda").to(torch.bfloat16) if epi == 2 else None
     row = []
     for kind in ("k64 NT", "k2 NT", "k64 NN", "k2 NN"):
-        L.csmae_gemm_k2_mode(2 * int(kind.startswith("k2")), 2 * int(kind.startswith("k2")))
+        L.csmae_gemm_k2_mode(3 * int(kind.startswith("k2")), 3 * int(kind.startswith("k2")))
         if kind.endswith("NT"):
             fn = (lambda: ops.gemm_ks(A, Wk, W, C, bias=bias, epilogue=epi, aux=aux, resid=resid)) if kind.startswith("k2") else (lambda: ops.gemm(A, W, C, bias=bias, epilogue=epi, aux=aux, resid=resid))
         else:
