@@ -712,7 +712,8 @@ class Engine:
         # chunk IS a view and the per-patch kind needs no whole-tensor statistics (bce's min / max, the ssim family).
         view_heads = two and ssim is None and kind in ("mse", "l2", "mae", "l1")
 
-        emb_ready = []
+        emb_ready, heads_done = [], []
+        crop_heads_aux = view_heads and self.has_pred and ops._timer is None and not debug_opt("crop_heads_main")
 
         def predictor_fwd(st):
             bn = "predictor.1."
@@ -754,13 +755,23 @@ class Engine:
                 yield
             ops.layernorm_fwd(ws.dec["x"][c["Nd"]][rd_], P("decoder_norm.weight"), P("decoder_norm.bias"), ws.emb_lp[rd_], ws.dn_st[0][rd_],
                               ws.dn_st[1][rd_], y32=ws.emb32[rd_], st=st)
+            hst = st
             if view_heads and b0 > 0 and self.has_pred:   # the crop's decoder output exists: the predictor (on the main stream, below) may start
                 emb_ready.append(torch.cuda.Event())
                 emb_ready[0].record(stream_obj)
-            ops.gemm(ws.emb_lp[rd_], self._w_pred()[: c["P"]], ws.pred[rd_], bias=P("decoder_pred.bias"), st=st)
+                if crop_heads_aux:
+                    # ... and the crop's own reconstruction head (decoder_pred product + per-patch loss, ~75 us, nothing depends on it before the
+                    # loss sum) moves to the auxiliary stream: on the main stream it stood between the crop's decoder_norm and the predictor chain,
+                    # the longest tail of the forward pass
+                    self.aux.wait_event(emb_ready[0])
+                    hst = self.aux.cuda_stream
+            ops.gemm(ws.emb_lp[rd_], self._w_pred()[: c["P"]], ws.pred[rd_], bias=P("decoder_pred.bias"), st=hst)
             if view_heads:   # (a chunk is a view here: samples [0, N) = the original, [N, 2N) = the crop)
                 ops.recon_loss_fwd(kind, npx, img0 if b0 == 0 else img1, None, ws.pred[rd_], None, ws.rowloss[b0 * L:(b0 + nb) * L], nb, nb,
-                                   c["C"], c["S"], c["p"], mask=ws.mask[b0:b0 + nb], st=st)
+                                   c["C"], c["S"], c["p"], mask=ws.mask[b0:b0 + nb], st=hst)
+            if hst is not st:
+                heads_done.append(torch.cuda.Event())
+                heads_done[0].record(self.aux)
 
         if two:
             # The two views are independent until the losses: view 1 runs on the second stream.  Its kernels fill the CUs that view
@@ -841,6 +852,8 @@ class Engine:
             if ce_done is not None:
                 torch.cuda.current_stream().wait_event(ce_done)
             kw.update(ce_rowloss=ws.ce_rowloss, ce_rows=B2)
+        if heads_done:
+            torch.cuda.current_stream().wait_event(heads_done[0])
         rscale = 0.5 if (self.views == 2 and c["reduction"] == "mean") else 1.0
         ops.loss_finalize(N * L, self.views, ws.rowloss, ws.mask, rscale, ws.losses, st=st, **kw)
         if ssim is not None:
