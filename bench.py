@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cross-scale-mae_amd"))
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz (MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0                 # HBM3E peak, TB/s (MI355X_MICROARCH.md; ~6.3 achievable)
 PEAK_FP8_TFLOPS = 5033.2           # dense fp8 MFMA peak (2 x bf16; MI355X_MICROARCH.md) — the roof BASELINE.json configs[4] is priced against
 GFLOP_PER_IMAGE = 118.80           # SURVEY.md §8(d), config 2, fwd + bwd (= 3 x 39.599)
 BATCH_PER_GPU, INPUT, PATCH = 128, 224, 16
@@ -52,6 +53,26 @@ def build(device, batch, world, loss="mse", preset="base"):
     opt = FusedAdamW(add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95))
     wrapped = DataParallel(model) if world > 1 else model
     return model, wrapped, opt
+
+
+# Algorithmic HBM bytes of one step: every activation / gradient tensor of a transformer block counted once per kernel that
+# must read or write it, in units of one [tokens, width] bf16 matrix — forward 28 units per block (LayerNorm 2 + 2, qkv 1 + 3, attention
+# 3 + 1, proj 3, fc1 1 + 4 + 2 (h and the 8-bit gelu'), fc2 4 + 2), backward 50 (fc2-dX 7, its dW 5, fc1-dX 5, its dW 5, LayerNorm 4 + 4,
+# proj-dX 2, its dW 2, attention 8, qkv-dX 4, its dW 4) — plus AdamW (28 B / parameter), the gradient clear (4 B / parameter) and the
+# images (two views read by patch-gather and by both reconstruction kernels).  Operand re-reads across tiles, split-K slabs and the heads /
+# stem (< 3 %) are NOT in it: the gap between this figure and the PMC traffic is what the kernels waste.
+BLOCK_UNITS = 28 + 50
+GEOM = {"base": (768, 12, 512, 8), "large": (1024, 24, 512, 8), "large4": (1024, 24, 512, 8), "huge14": (1280, 32, 512, 8)}   # D, Ne, Dd, Nd
+
+
+def algorithmic_hbm_gb(preset, batch, n_params):
+    _, size, patch, chans = PRESETS[preset][:4]
+    D, Ne, Dd, Nd = GEOM[preset]
+    L = (size // patch) ** 2
+    keep = int(L * 0.25)
+    Me, Md = 2 * batch * (keep + 1), 2 * batch * (L + 1)
+    acts = BLOCK_UNITS * 2 * (Ne * Me * D + Nd * Md * Dd)
+    return (acts + 32 * n_params + 3 * 2 * batch * chans * size * size * 4) / 1e9
 
 
 def csrc_hash():
@@ -345,6 +366,18 @@ def main():
         ach = ips / world * gflop / 1e3  # TFLOP/s per GPU
         scale = a.batch == BATCH_PER_GPU and a.loss == "mse" and a.preset == "base" and a.dtype == "bf16"
         peak = PEAK_FP8_TFLOPS if a.dtype == "fp8" else PEAK_BF16_TFLOPS
+        # which roof binds: the MFMA floor (algorithmic FLOP at the dense peak) against the HBM floor (measured traffic — or, without a valid
+        # PMC profile, the algorithmic bytes — at the 8 TB/s peak); `frac` stays the fraction of the MFMA peak BASELINE.json's north_star asks for
+        n_params = sum(p.numel() for p in model.parameters())
+        alg_gb = algorithmic_hbm_gb(a.preset, a.batch, n_params)
+        step_gb = traffic["step_hbm_gb"] if (traffic and scale) else None
+        ms = 1e3 * elapsed / a.steps
+        mfma_floor_ms = a.batch * gflop / peak
+        hbm_floor_ms = (step_gb if step_gb is not None else alg_gb) / PEAK_HBM_TBS
+        hbm = {"step_gb": step_gb, "algorithmic_gb": round(alg_gb, 1), "tb_per_s": round(step_gb / ms, 3) if step_gb is not None else None,
+               "frac_of_8": round(step_gb / ms / PEAK_HBM_TBS, 4) if step_gb is not None else None,
+               "algorithmic_tb_per_s": round(alg_gb / ms, 3), "floor_ms": round(hbm_floor_ms, 2), "floor_ms_at_6p3": round(hbm_floor_ms * PEAK_HBM_TBS / 6.3, 2),
+               "mfma_floor_ms": round(mfma_floor_ms, 2), "peak_tb_per_s": PEAK_HBM_TBS}
         out = {
             "metric": "pretrain images/sec ViT-B/16 224^2 two-scale", "value": round(ips, 2), "unit": "images/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
@@ -355,7 +388,7 @@ def main():
                        "headline_config": bool(scale)},
             "loss": round(final_loss, 5), "library_source_sha256": csmae_hip.source_hash()[:16],
             "chip": dict(chip_info(local), **watch.summary()),
-            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "roofline": {"bound": "hbm" if hbm_floor_ms > mfma_floor_ms else "mfma", "hbm": hbm, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic if (a.preset == "base" and a.dtype == "bf16" and scale) else None, "algorithmic_gflop_per_image": gflop, "dominant_kernel": kernel},
         }
         if dp_check is not None:

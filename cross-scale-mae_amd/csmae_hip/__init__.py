@@ -92,6 +92,18 @@ def debug_opt(name: str, default=None):
     return default
 
 
+# variables that used to be read on their own and are now keys of CSMAE_DEBUG: setting one changes nothing any more, so say so once
+_RETIRED_ENV = {"CSMAE_DW_SLOTS": "dw_slots", "CSMAE_DW_CUS": "dw_cus", "CSMAE_MAIN_CUS": "main_cus", "CSMAE_ZERO_MAIN": "zero_main",
+                "CSMAE_BWD_MAIN_CUS": "bwd_main_cus", "CSMAE_DW_GROUP": "dw_group", "CSMAE_K2_STAGGER": "k2_stagger"}
+
+
+def _warn_retired_env():
+    import warnings
+    for old, key in _RETIRED_ENV.items():
+        if os.environ.get(old) is not None:
+            warnings.warn(f"{old} is no longer read: use CSMAE_DEBUG={key}=... (INTEGRATION.md); this run uses the default", RuntimeWarning, stacklevel=3)
+
+
 _lib = None
 
 
@@ -117,6 +129,7 @@ def load():
         fn.restype = c_int
     if lib.csmae_abi_version() != ABI_VERSION:
         raise CsmaeError("libcsmae_hip ABI version mismatch")
+    _warn_retired_env()
     _lib = lib
     return lib
 

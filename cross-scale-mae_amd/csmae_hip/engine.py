@@ -261,7 +261,6 @@ class Engine:
         self.gen = 0            # forward() counter: an autograd node may only run the backward of the forward it belongs to
         self._gen_done = -1
         self.side, self.main, self.aux = None, None, None
-        self._ks_event, self._ks_pending = None, False
         self._fwd_streams = []
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
@@ -337,20 +336,26 @@ class Engine:
             # on the auxiliary stream, under the stem (crop, masking, patch embedding: ~0.2 ms before the first block needs a weight): the
             # 90-us launch is off the main chain; _ks_wait() orders the first consumer behind it
             cur = torch.cuda.current_stream()
+            # (the event lives on the FlatParams like the stamp: every engine of the model — training, stand-alone halves, one per dtype —
+            # must order its first consumer behind a refresh whichever engine launched it)
             if self.aux is not None and ops._timer is None:
                 self.aux.wait_stream(cur)   # the optimizer's writes to the bf16 mirror
                 ops.weights_kslab(f.ks_desc, f.w_lp, f.w_ks, st=self.aux.cuda_stream)
-                self._ks_event = self._ks_event or torch.cuda.Event()
-                self._ks_event.record(self.aux)
-                self._ks_pending = True
+                f.ks_event = getattr(f, "ks_event", None) or torch.cuda.Event()
+                f.ks_event.record(self.aux)
+                f.ks_waited = set()      # streams that have been ordered behind this refresh
             else:
                 ops.weights_kslab(f.ks_desc, f.w_lp, f.w_ks)
             f.ks_stamp = stamp
 
     def _ks_wait(self):
-        if self._ks_pending:
-            torch.cuda.current_stream().wait_event(self._ks_event)
-            self._ks_pending = False
+        f = self.flat
+        waited = getattr(f, "ks_waited", None)
+        if waited is not None:
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream not in waited:
+                cur.wait_event(f.ks_event)
+                waited.add(cur.cuda_stream)
 
     def _w_pe(self):
         if self.T == BF16 and self.Pp != self.cfg["P"]:
@@ -512,7 +517,7 @@ class Engine:
         return self._events[self._ev_i - 1]
 
     def _new_side(self):
-        """The weight-gradient stream.  CSMAE_DW_CUS=n confines it to n compute units of every XCD (ops.cu_masked_stream) instead of letting its
+        """The weight-gradient stream.  CSMAE_DEBUG=dw_cus=n confines it to n compute units of every XCD (ops.cu_masked_stream) instead of letting its
         160-workgroup launches time-slice whole CUs with the main chain; the forward's second-view stream is then a stream of its own."""
         n = int(debug_opt("dw_cus", "0"))
         if n <= 0:
@@ -976,7 +981,7 @@ class Engine:
             # The gradient clear (455 MB for ViT-B) runs on the weight-gradient stream, which is idle between the forward and the backward
             # pass, beside the reconstruction head's backward on the main stream: every weight-gradient launch follows it in stream order,
             # the main stream's own writers into the buffer (BatchNorm / LayerNorm / token gradients) wait for `zeroed` below.
-            if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN") or debug_opt("zero_main"):   # (CSMAE_ZERO_MAIN: A/B aid)
+            if ops._timer is not None or os.environ.get("CSMAE_DW_MAIN") or debug_opt("zero_main"):   # (CSMAE_DEBUG=zero_main: A/B aid)
                 self.flat.g[: self.flat.total].zero_()
             else:
                 self.side.wait_stream(self.main)

@@ -146,6 +146,7 @@ def gemm_ks(a, bk, b_plain, out, *, bias=None, epilogue=EPI_NONE, aux=None, resi
     N = b_plain.shape[0]
     assert b_plain.shape[1] == K and out.shape == (M, N) and a.stride(1) == 1 and out.stride(1) == 1 and b_plain.stride(1) == 1
     assert resid is None or resid.dtype == out.dtype
+    assert bk.dtype == torch.bfloat16 and bk.is_contiguous() and bk.numel() >= N * K, "gemm_ks: the K-slab mirror is a flat bf16 tensor of N * K elements"
     if aux is not None and aux.dtype == torch.uint8:
         epilogue = {EPI_GELU: 6, EPI_DGELU: 7}[epilogue]
     if _timer is not None:

@@ -76,7 +76,9 @@ const char* csmae_debug_opt(const char* key) {
   const size_t kl = strlen(key);
   for (const char* p = env; *p;) {
     const char* e = strchr(p, ',');
-    const size_t len = e ? (size_t)(e - p) : strlen(p);
+    size_t len = e ? (size_t)(e - p) : strlen(p);
+    while (len && (*p == ' ' || *p == '\t')) { ++p; --len; }                      // the Python reader (csmae_hip.debug_opt) strips items: so does this one
+    while (len && (p[len - 1] == ' ' || p[len - 1] == '\t')) --len;
     if (len >= kl && strncmp(p, key, kl) == 0 && (len == kl || p[kl] == '=')) {
       std::string& v = found[key];
       v = len == kl ? "1" : std::string(p + kl + 1, len - kl - 1);

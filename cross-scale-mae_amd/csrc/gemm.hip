@@ -970,9 +970,13 @@ static int g_k2_nt = k2_env(0, 2);
 // (gpurun_out/r05k-m): alone on the chip 1 is 25 % faster at 128 slots (it spreads over all 256 CUs), 0-8 % slower at 160 / 256; in the step
 // +0.55 ms at the best slot setting (21.85 vs 21.30 ms): the main chain loses more to 12 DMA pieces per wave and K step on every CU than its
 // LayerNorm / attention kernels gain from finding half a CU free.  Kept as an option (csmae_gemm_dw_mode) with its tests.
-static int g_k2_dw = k2_env(2, 0);
+static int g_k2_dw = 0;   // (CSMAE_K2's third field is ignored unless the build has the kernel: csmae_gemm_dw_mode)
 extern "C" int csmae_gemm_k2_mode(int nn, int nt) { g_k2_nn = nn; g_k2_nt = nt; return 0; }
-extern "C" int csmae_gemm_dw_mode(int k2) { g_k2_dw = k2; return 0; }
+bool gemm_k2_dw_built();   // gemm_k2.hip
+extern "C" int csmae_gemm_dw_mode(int k2) {
+  if (k2 && !gemm_k2_dw_built()) { csmae_set_error("csmae_gemm_dw_mode(1): the two-workgroups-per-CU weight-gradient kernel is not in this build (-DCSMAE_K2_DW)"); return CSMAE_ERR_UNSUPPORTED; }
+  g_k2_dw = k2; return 0;
+}
 int gemm_force_cfg() { return g_force_cfg; }
 static bool k2_wanted(int mode, int epilogue, long long K, long long N, long long M) {
   // size bounds (all modes but 3 = force): the kernel stages 1.5x the bytes of the 256 x 256 tile, which a weight that fits an XCD's L2 hides and a

@@ -228,25 +228,28 @@ template <bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_k2_kernel(GemmArgs p) {
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  // Phase offset between the two workgroups of a CU.  A launch's first 512 workgroups start together and every tile takes the same time, so the
-  // pair on a CU would stay IN phase for the whole launch — both in their loops, then both in their epilogues with the matrix pipes idle: the
-  // overlap this kernel exists for would never happen (measured: same tile time as alone).  The second workgroup of every CU (ids 256 .. 511:
-  // the dispatcher deals the first 256 one per CU) therefore sleeps about half a tile time once; equal tile times keep the offset afterwards.
+#if K2_ABL & 32
+  // Phase offset between the two workgroups of a CU (ablation build only: -DK2_ABL=32, tools/k2_variants.sh).  A launch's first 512 workgroups start
+  // together and every tile takes the same time, so the pair on a CU stays IN phase for the whole launch; here the second workgroup of every CU
+  // (ids 256 .. 511) sleeps about half a tile time once.  Measured (gpurun_out/r05d): the delayed workgroup's loop runs at 2 100 instead of 2 480
+  // clocks per K step and the launch as a whole no faster — a workgroup alone on the matrix pipes is bound by its own DMA issue.  Not in the product.
   if (blockIdx.x >= 256 && blockIdx.x < 512) {
     for (int i = (int)p.split_stride; i > 0; --i) __builtin_amdgcn_s_sleep(127);   // 127 x 64 clocks per iteration
   }
+#endif
   k2_tile<TB>(p, tm, tn);
 }
-// Clocks the second workgroup of a CU sleeps at the start of a launch (CSMAE_DEBUG=k2_stagger=a:b: a + b * K steps clocks; default none).  Measured
-// (gpurun_out/r05d): with half a tile time of offset the delayed workgroup's loop runs at 2 100 instead of 2 480 clocks per K step, the launch
-// as a whole no faster — a workgroup alone on the matrix pipes is bound by its own DMA issue (12 pieces per wave and step), not by the pipe.
-static long long k2_stagger_sleeps(int nsteps, int epi) {
+#if K2_ABL & 32
+static long long k2_stagger_sleeps(int nsteps, int epi) {   // CSMAE_DEBUG=k2_stagger=a:b: a + b * K steps clocks (ablation build only)
   static int a = -1, b = -1;
   if (a < 0) { const char* e = csmae_debug_opt("k2_stagger"); if (!e || sscanf(e, "%d:%d", &a, &b) != 2) { a = 0; b = 0; } }
   if (a == 0 && b == 0) return 0;
   const long long clk = a + (long long)b * nsteps + ((epi == EPI_GELU || epi == EPI_DGELU) ? 4000 : 0);
   return clk / (127 * 64);
 }
+#else
+static long long k2_stagger_sleeps(int, int) { return 0; }
+#endif
 int gemm_k2_launch_nn(const GemmArgs& p0, hipStream_t st) {
   GemmArgs p = p0;
   p.split_stride = k2_stagger_sleeps(p.ktiles, p.epi);
@@ -261,8 +264,8 @@ extern "C" int csmae_gemm_ks(int dtype, long long M, long long N, long long K, c
                              const void* B_plain, long long ldb_plain, void* C, long long ldc, int c_dtype, const float* bias, int epilogue,
                              void* aux, long long ldaux, const void* resid, long long ldr, void* stream) {
   const int epi_kind = epilogue == 6 ? EPI_GELU : (epilogue == 7 ? EPI_DGELU : epilogue);
-  const bool ok = dtype == CSMAE_BF16 && Bk && gemm_k2_nt_wanted(epi_kind, K, N, M) && (gemm_force_cfg() < 0 || (gemm_force_cfg() & 7) == 6) && K % 64 == 0 && M >= 128 && N >= 256 && N % 4 == 0 && ldc % 4 == 0 &&
-                  lda % 8 == 0 && slab_rows >= N && (M + 128) * lda * 2 < 0xFFFFFFF0ll && (K / 32) * slab_rows * 64 < 0xFFFFFFF0ll &&
+  const bool ok = dtype == CSMAE_BF16 && Bk && gemm_k2_nt_wanted(epi_kind, K, N, M) && (gemm_force_cfg() < 0 || (gemm_force_cfg() & 7) == 6) && K >= 64 && K % 64 == 0 && M >= 128 && N >= 256 && N % 4 == 0 && ldc % 4 == 0 && ldc >= N &&
+                  lda % 8 == 0 && lda >= K && slab_rows >= N && slab_rows % 4 == 0 && (M + 128) * lda * 2 < 0xFFFFFFF0ll && (K / 32) * slab_rows * 64 < 0xFFFFFFF0ll &&
                   (((uintptr_t)A | (uintptr_t)Bk | (uintptr_t)C) & 15) == 0;
   if (!ok) {
     CSMAE_REQUIRE(B_plain != nullptr, "csmae_gemm_ks: shape not taken by the K-slab kernel and no plain weight given (M=%lld N=%lld K=%lld)", M, N, K);
@@ -316,6 +319,9 @@ extern "C" int csmae_weights_kslab(int count, const long long* desc, int max_blo
 }
 
 
+// (round 5 option, measured +0.55 ms in the step: compiled only with -DCSMAE_K2_DW — tools/k2_variants.sh; the product library answers
+// csmae_gemm_dw_mode(1) with CSMAE_ERR_UNSUPPORTED)
+#ifdef CSMAE_K2_DW
 // ------------------------------------------------------------------------------------ weight gradients on the two-workgroups-per-CU structure
 // dW[M = out][N = in] += sum_k dY[k][m] X[k][n]: both operands K-strided (token-major), i.e. every fragment is two transposing reads
 // (ds_read_b64_tr_b16).  The one-workgroup kernel (k64_tile<true, true>) leaves those reads to the compiler and runs 3 000 - 3 500 clocks per K
@@ -594,4 +600,17 @@ int gemm_k2_launch_dw(DwGroupArgs& ga, int count, int slots, float* workspace, l
   hipLaunchKernelGGL(gemm_dw_group_k2_kernel, dim3(tiles * ga.nsplit), dim3(256), 0, st, ga);
   if (ga.nsplit > 1) hipLaunchKernelGGL(dw_group_reduce_k2_kernel, dim3(tiles * DWR_PARTS), dim3(256), 0, st, ga);
   return csmae_check_launch("csmae_gemm_dw_group");
+}
+#else
+int gemm_k2_launch_dw(DwGroupArgs&, int, int, float*, long long, hipStream_t) {
+  csmae_set_error("csmae_gemm_dw_group: the two-workgroups-per-CU weight-gradient kernel is not in this build (-DCSMAE_K2_DW)");
+  return CSMAE_ERR_UNSUPPORTED;
+}
+#endif
+bool gemm_k2_dw_built() {
+#ifdef CSMAE_K2_DW
+  return true;
+#else
+  return false;
+#endif
 }

@@ -40,8 +40,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict_
       *reinterpret_cast<f4_t*>(p + off + i) = pp; *reinterpret_cast<f4_t*>(m + off + i) = mm; *reinterpret_cast<f4_t*>(v + off + i) = vv;
       if (p_lp) st4<bf16_t>(p_lp + off + i, pp);
       if (ksK) {
-        const int e = (int)(off + i - wbase), n = e / ksK, k = e - n * ksK;
-        st4<bf16_t>(p_ks + wbase + ((long long)(k >> 5) * ksN + n) * 32 + (k & 31), pp);
+        const long long e = off + i - wbase;
+        const int n = (int)(e / ksK), k = (int)(e - (long long)n * ksK);
+        if ((k & 3) == 0 && k + 4 <= ksK) st4<bf16_t>(p_ks + wbase + ((long long)(k >> 5) * ksN + n) * 32 + (k & 31), pp);
+        else {   // (K % 4 != 0 or an unaligned slot: the four elements straddle a row or a 32-wide K group)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const long long eq = e + q;
+            const int nq = (int)(eq / ksK), kq = (int)(eq - (long long)nq * ksK);
+            p_ks[wbase + ((long long)(kq >> 5) * ksN + nq) * 32 + (kq & 31)] = f2bf(pp[q]);
+          }
+        }
       }
     } else {
       for (int k = i; k < cnt && k < i + 4; ++k) {
@@ -52,7 +61,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const long long* __restrict_
         p[off + k] = pp; m[off + k] = mm; v[off + k] = vv;
         if (p_lp) p_lp[off + k] = f2bf(pp);
         if (ksK) {
-          const int e = (int)(off + k - wbase), n = e / ksK, kk = e - n * ksK;
+          const long long e = off + k - wbase;
+          const int n = (int)(e / ksK), kk = (int)(e - (long long)n * ksK);
           p_ks[wbase + ((long long)(kk >> 5) * ksN + n) * 32 + (kk & 31)] = f2bf(pp);
         }
       }

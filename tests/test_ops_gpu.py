@@ -134,8 +134,9 @@ def test_gemm_dw_group_two_workgroups_per_cu_kernel(ops, case):
         dy = dev(rnd(K, M + pad, seed=300 + i).to(torch.bfloat16))[:, :M]
         x = dev(rnd(K, N + pad, seed=310 + i).to(torch.bfloat16))[:, :N]
         items.append((dy, x))
+    if lib.csmae_gemm_dw_mode(1) != 0:
+        pytest.skip("the two-workgroups-per-CU weight-gradient kernel is an ablation-build option (-DCSMAE_K2_DW): not in the product library")
     try:
-        lib.csmae_gemm_dw_mode(1)
         runs = []
         for _ in range(2):
             outs = [(torch.full((dy.shape[1], x.shape[1]), 0.25, device="cuda"), torch.full((dy.shape[1],), 0.25, device="cuda")) for dy, x in items]
