@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 import torch  # noqa: F401  -- must come first: libcsmae_hip.so has to bind to the HIP runtime PyTorch already loaded (one runtime per process)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ATOMIC = 0, 1, 2, 3, 4
 LOSS_KINDS = {"mse": 0, "l2": 1, "mae": 2, "l1": 3, "bce": 4, "none": 5}
 # the ssim family: kind -> (per-patch kind, pyramid levels, weight of the ssim term)  MAE_ViT_Shared.py:165-267
@@ -26,6 +26,9 @@ _SIGNATURES = {
     "csmae_gemm": [I, I, I, L, L, L, P, L, P, L, P, L, I, P, I, P, L, P, L, I, P],
     "csmae_gemm_ks": [I, L, L, L, P, L, P, L, P, L, P, L, I, P, I, P, L, P, L, P],
     "csmae_weights_kslab": [I, P, I, P, P, P],
+    "csmae_gemm_ln_supported": [L, L, L],
+    "csmae_gemm_ln_fwd": [L, L, L, P, L, P, L, P, P, L, P, L, P, P, F, P, L, P, P, P],
+    "csmae_gemm_ln_bwd": [L, L, L, P, L, P, L, P, L, P, P, P, P, L, P, L, P, L, P],
     "csmae_gemm_k2_mode": [I, I],
     "csmae_gemm_dw_mode": [I],
     "csmae_gemm_dw": [I, L, L, L, P, L, P, L, P, P, P, L, P],
@@ -43,6 +46,7 @@ _SIGNATURES = {
     "csmae_layernorm_fwd": [I, I, L, I, P, P, P, F, P, P, P, P, P, I, P, P, P, P],
     "csmae_layernorm_bwd": [I, I, I, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P, I, P, P, P, P],
     "csmae_ln_param_reduce": [I, L, I, P, L, L, P, P, P],
+    "csmae_ln_param_reduce_rows": [I, I, I, P, L, P, P, P],
     "csmae_bnrelu_fwd": [I, I, I, I, P, P, P, F, F, P, P, P, P, P, P, I, P],
     "csmae_bnrelu_bwd": [I, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "csmae_crop_resize": [L, I, P, P, P, P],

@@ -206,8 +206,9 @@ class Workspace:
         self.dtok_lp = E(B2 * max(keep, 1), D, **lp)
         # per-block dgamma / dbeta partial rows of every LayerNorm backward of the step (one slice each), folded by ONE launch per
         # block stack at the end instead of one small reduce per LayerNorm on the critical path
-        self.ln_part_e = E(2 * c["Ne"], 1024 * 2 * D, **f32)
-        self.ln_part_d = E(2 * c["Nd"] + 1, 1024 * 2 * Dd, **f32)
+        # (<= 1024 rows per LayerNorm from csmae_layernorm_bwd, one per 128-row tile from csmae_gemm_ln_bwd)
+        self.ln_part_e = E(2 * c["Ne"], max(1024, -(-Me // 128)) * 2 * D, **f32)
+        self.ln_part_d = E(2 * c["Nd"] + 1, max(1024, -(-Md // 128)) * 2 * Dd, **f32)
         if eng.fp8:   # fp8 staging of the A operand (one buffer per forward stream) and the per-GEMM scale scalars of a step
             big8 = max(Me * 4 * D, Md * 4 * Dd)
             self.a8 = [E(big8, device=dev, dtype=torch.uint8) for _ in range(2)]
@@ -271,6 +272,11 @@ class Engine:
                 raise ValueError(f"CSMAE_DEBUG {key}={v!r}: expected lo:hi (mask bits of the compute units)")
         if not str(debug_opt("dw_cus", "0")).isdigit():
             raise ValueError(f"CSMAE_DEBUG dw_cus={debug_opt('dw_cus')!r}: expected the number of CUs per XCD")
+        # LayerNorm inside the GEMM epilogues of the stacks whose rows fit one workgroup (csmae_gemm_ln_fwd / _bwd: width <= 512, i.e. the decoders):
+        # proj + norm2, fc2 + the next block's norm1, fc1-dX + norm2', qkv-dX + norm1'.  bf16 throughput mode with the bf16 residual stream only.
+        self.ln_fuse = self.T == BF16 and not self.fp8 and self.res_dtype == torch.bfloat16 and not debug_opt("no_lnfuse")
+        self.ln_fuse_fwd = self.ln_fuse and not debug_opt("no_lnfuse_fwd")   # (A/B aids: one direction only)
+        self.ln_fuse_bwd = self.ln_fuse and not debug_opt("no_lnfuse_bwd")
         self.use_ks = not debug_opt("no_kslab")   # (CSMAE_DEBUG=no_kslab: forward products through csmae_gemm with the plain weight mirror; no K-slab mirror is kept)
         self._dw_slots = int(debug_opt("dw_slots", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
@@ -547,21 +553,45 @@ class Engine:
         Mr = y1.shape[0]
         k1 = self._fp8_alloc()
         e1 = self._emit(k1, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
-        ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, st=st)
+        fuse = self._ln_fused_fwd(Mr, Dm)
+        if not (fuse and i > 0):   # (fused: the previous block's fc2 epilogue has already left norm1(x_in) in y1 and its statistics)
+            ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, st=st)
         self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=ln, site=k1, a8=e1[0] if e1 else None)
         # (fp8 mode) attention leaves its output as fp8 bytes for attn.proj (q_a: y1 has been consumed by the qkv GEMM, y2 comes after proj)
         ko = self._fp8_alloc()
         eo = self._emit(ko, ws_q_a[ln], Mr, Dm, 0) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
         ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, emit=eo, st=st)
-        self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0), site=ko,
-                 a8=eo[0] if eo else None)
-        k2 = self._fp8_alloc()
-        e2 = self._emit(k2, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
-        ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], emit=e2, st=st)
+        k2 = None
+        if fuse:   # x_mid = x_in + proj(o) and y2 = norm2(x_mid) in one kernel
+            ops.gemm_ln_fwd(o, self._ks(pre + "attn.proj.weight"), P(pre + "attn.proj.bias"), x_in, x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"),
+                            y2, stt[2], stt[3], st=st)
+            e2 = None
+        else:
+            self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0), site=ko,
+                     a8=eo[0] if eo else None)
+            k2 = self._fp8_alloc()
+            e2 = self._emit(k2, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
+            ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], emit=e2, st=st)
         kh = self._fp8_alloc()   # (fp8 mode) the site of fc2's A operand: h leaves the fc1 epilogue as bf16 AND as fp8 bytes
         eh = self._emit(kh, self.ws.q_b[ln], Mr, 4 * Dm, 0) if self.fp8 else None
         self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=ln, site=k2, a8=e2[0] if e2 else None, emit_site=kh)
-        self._mm(h, pre + "mlp.fc2.weight", x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st, lane=ln, site=kh, a8=eh[0] if eh else None)
+        if fuse and i + 1 < S["xm"].shape[0]:   # x_out = x_mid + fc2(h) and the NEXT block's y1 = norm1(x_out) in one kernel
+            nxt = pre[: pre.rstrip(".").rfind(".") + 1] + f"{i + 1}."
+            sn = [a[r] for a in S["st"][i + 1][:2]]
+            ops.gemm_ln_fwd(h, self._ks(pre + "mlp.fc2.weight"), P(pre + "mlp.fc2.bias"), x_mid, x_out, P(nxt + "norm1.weight"), P(nxt + "norm1.bias"),
+                            S["y1"][i + 1][r], sn[0], sn[1], st=st)
+        else:
+            self._mm(h, pre + "mlp.fc2.weight", x_out, bias=P(pre + "mlp.fc2.bias"), epilogue=EPI_RESID, resid=x_mid, st=st, lane=ln, site=kh, a8=eh[0] if eh else None)
+
+    def _ks(self, name):
+        o, cnt, _ = self.flat.slots[name]
+        return self.flat.w_ks[o:o + cnt]
+
+    def _ln_fused_fwd(self, M, Dm):
+        return self.ln_fuse_fwd and self.use_ks and ops.gemm_ln_supported(M, Dm, Dm)
+
+    def _ln_fused_bwd(self, M, Dm):
+        return self.ln_fuse_bwd and ops.gemm_ln_supported(M, Dm, 4 * Dm)
 
     def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, k, part):
         """`lps` = the rotating low-precision copies of the residual gradient, lps[k] is current on entry; returns the index that is
@@ -615,11 +645,19 @@ class Engine:
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, ready=ev1)
         elif mode == "none":
             self._dw(dpre, y2, pre + "mlp.fc1")
-        self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
-        self._guard_write(nxt)
-        kn = self._fp8_alloc()
-        en = self._emit(kn, ws.q_a[0], M, Dm, 1) if (self.fp8 and self._fp8_fuse_lnb) else None
-        if dres is None:
+        fuse = dres is None and self._ln_fused_bwd(M, Dm)
+        if fuse:   # fc1's dX product, norm2's backward and the residual-gradient add in one kernel: the product never reaches HBM
+            self._guard_write(nxt)
+            ops.gemm_ln_bwd(dpre, self.W(pre + "mlp.fc1.weight"), S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), cur, nxt, partial_ws=part[1], st=st)
+            kn, en = None, None
+        else:
+            self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
+            self._guard_write(nxt)
+            kn = self._fp8_alloc()
+            en = self._emit(kn, ws.q_a[0], M, Dm, 1) if (self.fp8 and self._fp8_fuse_lnb) else None
+        if fuse:
+            pass
+        elif dres is None:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), nxt, None, None, dres_in=cur, partial_ws=part[1], emit=en, st=st)
         else:
             ops.layernorm_bwd(t1, S["xm"][i], stt[2], stt[3], P(pre + "norm2.weight"), dres, None, None, dres_in=dres, dx_lp=nxt, partial_ws=part[1], st=st)
@@ -641,6 +679,10 @@ class Engine:
             self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2)
         else:
             self._dw(dqkv, y1, pre + "attn.qkv")
+        if fuse:   # qkv's dX product + norm1's backward + the residual-gradient add
+            self._guard_write(out)
+            ops.gemm_ln_bwd(dqkv, self.W(pre + "attn.qkv.weight"), S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), nxt, out, partial_ws=part[0], st=st)
+            return (k + 2) % n if rot else k
         self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st, site=kq, a8=eq[0] if eq else None)
         self._guard_write(out)
         kx = self._fp8_alloc() if i > 0 else None     # the next block's fc2-backward reads `out`
@@ -653,10 +695,14 @@ class Engine:
             self._fp8_cur = (kx, ex[0] if ex else None)
         return (k + 2) % n if rot else k
 
-    def _ln_flush(self, part, goff, lo, hi, M, Dm):
-        """dgamma / dbeta of LayerNorms [lo, hi) of a stack (rows of `part` / `goff`): one deterministic launch."""
+    def _ln_flush(self, part, goff, lo, hi, M, Dm, fused=False):
+        """dgamma / dbeta of LayerNorms [lo, hi) of a stack (rows of `part` / `goff`): one deterministic launch.  `fused`: their partial rows were
+        left by the GEMM epilogues (csmae_gemm_ln_bwd: one row per 128-row tile)."""
         if hi > lo:
-            ops.ln_param_reduce(hi - lo, M, Dm, part[lo:hi], goff[lo:hi], self.flat.g, st=self.st)
+            if fused:
+                ops.ln_param_reduce_rows(hi - lo, -(-M // 128), Dm, part[lo:hi], goff[lo:hi], self.flat.g, st=self.st)
+            else:
+                ops.ln_param_reduce(hi - lo, M, Dm, part[lo:hi], goff[lo:hi], self.flat.g, st=self.st)
 
     # ------------------------------------------------------------------ forward
     def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool,
@@ -1065,7 +1111,11 @@ class Engine:
         kd_ = 0
         for i in reversed(range(c["Nd"])):
             kd_ = self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp, kd_, (pd[2 * i], pd[2 * i + 1]))
-        self._ln_flush(pd, self._goff_d, 0, Nd2 + 1, ws.Md, Dd)
+        if lp_stream and self._ln_fused_bwd(ws.Md, Dd):   # the blocks' LayerNorms left one partial row per GEMM tile, decoder_norm's kernel its own count
+            self._ln_flush(pd, self._goff_d, 0, Nd2, ws.Md, Dd, fused=True)
+            self._ln_flush(pd, self._goff_d, Nd2, Nd2 + 1, ws.Md, Dd)
+        else:
+            self._ln_flush(pd, self._goff_d, 0, Nd2 + 1, ws.Md, Dd)
         ops.unshuffle_bwd(ws.dres_d_lp[kd_] if lp_stream else ws.dres_d, ws.ids_restore, ws.dz_lp, G("mask_token").view(Dd), B2, L, keep, st=st)
         lat_op = ws.enc["x"][c["Ne"]] if (lp_stream or self.T != BF16) else ws.lat_lp
         self._dw(ws.dz_lp, lat_op, "decoder_embed")
@@ -1088,14 +1138,15 @@ class Engine:
         ops.latent_grad_finish(ws.dres_e, dpool, 1.0 / keep, ws.dres_e_lp[0], B2, Te, st=st)
         self._fp8_cur = None
         pe, flushed = ws.ln_part_e, c["Ne"]
+        fe = lp_stream and self._ln_fused_bwd(ws.Me, D)
         ke_ = 0
         for i in reversed(range(c["Ne"])):
             ke_ = self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, None if lp_stream else ws.dres_e, ws.dres_e_lp, ke_, (pe[2 * i], pe[2 * i + 1]))
             if dp is not None and dp.wants(("enc", i)):
-                self._ln_flush(pe, self._goff_e, 2 * i, 2 * flushed, ws.Me, D)   # the bucket's LayerNorm gradients must be final before its exchange
+                self._ln_flush(pe, self._goff_e, 2 * i, 2 * flushed, ws.Me, D, fused=fe)   # the bucket's LayerNorm gradients must be final before its exchange
                 flushed = i
                 dp.grads_ready(self.flat, ("enc", i), also=self.side if not (ops._timer is not None or os.environ.get("CSMAE_DW_MAIN")) else None)
-        self._ln_flush(pe, self._goff_e, 0, 2 * flushed, ws.Me, D)
+        self._ln_flush(pe, self._goff_e, 0, 2 * flushed, ws.Me, D, fused=fe)
         ops.embed_assemble_bwd(ws.dres_e_lp[ke_] if lp_stream else ws.dres_e, ws.dtok_lp, G("cls_token").view(D), B2, keep, st=st)
         self._join_side()
         ops.DwGroup([(ws.dtok_lp, ws.a_pe[:, : c["P"]], G("patch_embed.proj.weight").view(D, c["P"]), G("patch_embed.proj.bias"))], ws.dw_ws).launch(256, st=st)

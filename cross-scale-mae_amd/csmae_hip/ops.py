@@ -159,6 +159,44 @@ def gemm_ks(a, bk, b_plain, out, *, bias=None, epilogue=EPI_NONE, aux=None, resi
     return out
 
 
+def gemm_ln_supported(M, N, K):
+    """True when csmae_gemm_ln_fwd / _bwd take the shape (whole output rows in one workgroup: N <= 512, N % 64 == 0, K % 64 == 0)."""
+    return load().csmae_gemm_ln_supported(M, N, K) == 1
+
+
+def gemm_ln_fwd(a, bk, bias, resid, x_out, gamma, beta, y, mean, rstd, eps=1e-6, st=None):
+    """x_out = a W^T + bias + resid; y = LayerNorm(x_out) * gamma + beta; mean / rstd of x_out — one kernel (csmae_gemm_ln_fwd).  `bk`: the K-slab
+    mirror of W [N, K] (flat bf16, N * K elements); a, resid, x_out, y bf16 [M, .]."""
+    M, K = a.shape
+    N = x_out.shape[1]
+    assert a.dtype == resid.dtype == x_out.dtype == y.dtype == bk.dtype == torch.bfloat16 and bk.is_contiguous() and bk.numel() >= N * K
+    assert resid.shape == x_out.shape == y.shape == (M, N) and a.stride(1) == resid.stride(1) == x_out.stride(1) == y.stride(1) == 1
+    assert mean.dtype == rstd.dtype == torch.float32 and mean.numel() >= M and rstd.numel() >= M and gamma.numel() == beta.numel() == N
+    if _timer is not None:
+        _timer.begin()
+    check(load().csmae_gemm_ln_fwd(M, N, K, _p(a), a.stride(0), _p(bk), N, _p(bias), _p(resid), resid.stride(0), _p(x_out), x_out.stride(0), _p(gamma), _p(beta),
+                                   eps, _p(y), y.stride(0), _p(mean), _p(rstd), st if st is not None else stream()), "csmae_gemm_ln_fwd")
+    if _timer is not None:
+        _timer.end("gemm_bf16_NT", 2.0 * M * N * K)
+
+
+def gemm_ln_bwd(dy, w, x, mean, rstd, gamma, dres_in, dx_out, partial_ws=None, st=None):
+    """dx_out = LayerNorm'(dy w; x, mean, rstd, gamma) + dres_in (w [K, N]: the layer's weight as torch stores it); partial_ws receives ceil(M / 128)
+    partial rows [2, N] of dgamma / dbeta for ln_param_reduce_rows — one kernel (csmae_gemm_ln_bwd)."""
+    M, K = dy.shape
+    N = w.shape[1]
+    assert w.shape[0] == K and x.shape == dx_out.shape == (M, N) and (dres_in is None or dres_in.shape == (M, N))
+    assert dy.dtype == w.dtype == x.dtype == dx_out.dtype == torch.bfloat16 and (dres_in is None or dres_in.dtype == torch.bfloat16)
+    assert dy.stride(1) == w.stride(1) == x.stride(1) == dx_out.stride(1) == 1 and mean.dtype == rstd.dtype == torch.float32
+    if _timer is not None:
+        _timer.begin()
+    check(load().csmae_gemm_ln_bwd(M, N, K, _p(dy), dy.stride(0), _p(w), w.stride(0), _p(x), x.stride(0), _p(mean), _p(rstd), _p(gamma), _p(dres_in),
+                                   dres_in.stride(0) if dres_in is not None else 0, _p(dx_out), dx_out.stride(0), _p(partial_ws),
+                                   partial_ws.numel() if partial_ws is not None else 0, st if st is not None else stream()), "csmae_gemm_ln_bwd")
+    if _timer is not None:
+        _timer.end("gemm_bf16_NN", 2.0 * M * N * K)
+
+
 def weights_kslab(desc, src, dst, max_blocks=64, st=None):
     """K-slab mirrors (csmae.h csmae_gemm_ks) of the weights in desc (int64 [count, 3] on the device: flat offset, out, in) from the bf16 mirror."""
     check(load().csmae_weights_kslab(desc.shape[0], _p(desc), max_blocks, _p(src), _p(dst), st if st is not None else stream()), "csmae_weights_kslab")
@@ -304,6 +342,12 @@ def ln_param_reduce(count, M, D, partials, goff, gbase, st=None):
     """partials [>= count, slice] fp32 (row k = LayerNorm k's partial rows), goff [count, 2] int64 offsets of dgamma / dbeta in gbase."""
     check(load().csmae_ln_param_reduce(count, M, D, _p(partials), partials.stride(0), partials.shape[1], _p(gbase), _p(goff),
                                        st if st is not None else stream()), "csmae_ln_param_reduce")
+
+
+def ln_param_reduce_rows(count, rows, D, partials, goff, gbase, st=None):
+    """The same fold for LayerNorms whose partial rows were left by gemm_ln_bwd: `rows` = ceil(M / 128) rows per LayerNorm."""
+    check(load().csmae_ln_param_reduce_rows(count, rows, D, _p(partials), partials.stride(0), _p(gbase), _p(goff), st if st is not None else stream()),
+          "csmae_ln_param_reduce_rows")
 
 
 def bnrelu_fwd(u, gamma, beta, r, mean, rstd, N, L, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, training=True, st=None):

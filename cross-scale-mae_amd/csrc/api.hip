@@ -21,7 +21,7 @@ int csmae_check_launch(const char* what) {
 }
 
 extern "C" const char* csmae_last_error(void) { return g_err; }
-extern "C" int csmae_abi_version(void) { return 6; }
+extern "C" int csmae_abi_version(void) { return 7; }
 
 // ---- an event attached to the next launch (common.h: CSMAE_LAUNCH).  The reference has no counterpart: torch records events behind kernels
 // (autograd's stream hand-offs, DDP's bucket hooks — main_pretrain.py:417-421); here the weight-gradient stream of csmae_hip/engine.py waits for

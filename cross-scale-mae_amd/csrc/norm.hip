@@ -254,6 +254,14 @@ extern "C" int csmae_ln_param_reduce(int count, long long M, int D, const float*
   return csmae_check_launch("csmae_ln_param_reduce");
 }
 
+// The same fold for partial rows that a GEMM epilogue left (csmae_gemm_ln_bwd: one row per 128-row tile): the caller names the row count.
+extern "C" int csmae_ln_param_reduce_rows(int count, int rows, int D, const float* partials, long long stride, float* gbase, const long long* goff, void* stream) {
+  CSMAE_REQUIRE(count > 0 && rows > 0 && D > 0 && partials && gbase && goff && stride >= 2ll * D * rows, "csmae_ln_param_reduce_rows: bad arguments");
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), count), dim3(1024), 0, (hipStream_t)stream, rows, D, partials, stride, gbase, goff,
+                     (float*)nullptr, (float*)nullptr);
+  return csmae_check_launch("csmae_ln_param_reduce_rows");
+}
+
 // ------------------------------------------------------------------------------------------ BatchNorm(token axis)+ReLU
 // u is [N*L, Hp]; channel = token position l; statistics over the N*Hp values {u[n*L + l, :]} (models_mae/MLP.py:7).
 template <typename T>

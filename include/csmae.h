@@ -67,6 +67,22 @@ int csmae_gemm_ks(int dtype, long long M, long long N, long long K, const void* 
 /* desc: device int64 [count][3] = {offset (elements) of weight i in src AND dst, out-features N, in-features K (K % 64 == 0)}; one launch of
  * (max_blocks, count) workgroups */
 int csmae_weights_kslab(int count, const long long* desc, int max_blocks, const void* src_bf16, void* dst_bf16, void* stream);
+/* ---- a Linear product of timm's Block WITH the LayerNorm next to it in its epilogue (ABI version 7; csrc/gemm_ln.hip): a 128 x 512 tile — eight
+ * waves side by side along N, one workgroup per CU — holds whole output rows (N <= 512, N % 64 == 0: the decoders), so the row statistics are made
+ * inside the workgroup.  All tensors bf16 (the throughput mode's residual stream); bias / gamma / beta / mean / rstd fp32; K % 64 == 0.
+ *   fwd  X = A Wk^T + bias + resid ; Y = LayerNorm(X; gamma, beta, eps) ; mean / rstd of X          [Wk: the K-slab mirror, as csmae_gemm_ks]
+ *        = `x = x + attn.proj(..)` -> `norm2(x)`, and `x = x + mlp.fc2(..)` -> the NEXT block's `norm1(x)`     (MAE_ViT_Baseline.py:160-188)
+ *   bwd  dx_out = LayerNorm'(dY W; x, mean, rstd, gamma) + dres_in ; partial_ws[ceil(M / 128)][2][N] = the tiles' dgamma / dbeta rows
+ *        (W [K][N] as torch stores the layer's weight, K = out-features) = the backward of `norm2 -> mlp.fc1` and `norm1 -> attn.qkv`; the
+ *        product itself never reaches HBM.  Same arithmetic as csmae_gemm + csmae_layernorm_bwd on the bf16-rounded product; fixed summation
+ *        order (bit-reproducible).  csmae_ln_param_reduce_rows folds the partial rows (rows = ceil(M / 128)). */
+int csmae_gemm_ln_supported(long long M, long long N, long long K);
+int csmae_gemm_ln_fwd(long long M, long long N, long long K, const void* A, long long lda, const void* Bk, long long slab_rows,
+                      const float* bias, const void* resid, long long ldr, void* X, long long ldx, const float* gamma, const float* beta,
+                      float eps, void* Y, long long ldy, float* mean, float* rstd, void* stream);
+int csmae_gemm_ln_bwd(long long M, long long N, long long K, const void* dY, long long lda, const void* W, long long ldb,
+                      const void* x, long long ldx, const float* mean, const float* rstd, const float* gamma, const void* dres_in, long long ldd,
+                      void* dx_out, long long ldo, float* partial_ws, long long partial_elems, void* stream);
 int csmae_gemm_k2_mode(int nn, int nt);
 int csmae_gemm_dw_mode(int k2);   /* csmae_gemm_dw_group on the 256 x 256 one-workgroup kernel (0, default) or the two-workgroups-per-CU one (1): measured slower in the step, kept as an option */
 
@@ -140,6 +156,8 @@ int csmae_layernorm_bwd(int dy_dtype, int x_dtype, int lp_dtype, long long M, in
  * M and D), dgamma at gbase + goff[2k], dbeta at gbase + goff[2k+1] (device array).  Fixed summation order, no atomics. */
 int csmae_ln_param_reduce(int count, long long M, int D, const float* partials, long long stride, long long slice_elems,
                           float* gbase, const long long* goff, void* stream);
+/* the same fold with the number of partial rows per LayerNorm given by the caller (csmae_gemm_ln_bwd leaves ceil(M / 128) of them); stride >= rows * 2 * D */
+int csmae_ln_param_reduce_rows(int count, int rows, int D, const float* partials, long long stride, float* gbase, const long long* goff, void* stream);
 
 /* ---- predictor BatchNorm1d(num_patches) + ReLU (models_mae/MLP.py:7-8): channel = token position, batch statistics
  * over (sample, feature); updates running stats (momentum, unbiased var) and num_batches_tracked in place. */

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()[-2:-1] == ["T"] and ln.split()[-1].startswith("csmae_")}
     assert exported == set(decl), (sorted(exported - set(decl)), sorted(set(decl) - exported))
     lib.csmae_abi_version.restype = ctypes.c_int
-    assert lib.csmae_abi_version() == csmae_hip.ABI_VERSION == 6
+    assert lib.csmae_abi_version() == csmae_hip.ABI_VERSION == 7
 
 
 def test_binding_arity_matches_header():

@@ -521,6 +521,108 @@ def test_layernorm_emits_fp8_copy(ops, fmt):
     assert bool(((deq - want).abs() <= tol).all()) and abs(float(nxt.max()) - float(want.abs().max())) <= 8e-3 * float(nxt.max())
 
 
+def _kslab_torch(w):
+    """K-slab mirror of w [N, K] (bf16): Wk[K/32][N][32], flat (csmae.h csmae_gemm_ks)."""
+    N, K = w.shape
+    return w.view(N, K // 32, 32).permute(1, 0, 2).contiguous().reshape(-1)
+
+
+LN_GEMM_SHAPES = [(128, 512, 512), (394, 512, 2048), (1000, 512, 1536), (77, 256, 64), (300, 384, 128), (25216, 512, 512)]
+
+
+@pytest.mark.parametrize("mnk", LN_GEMM_SHAPES)
+def test_gemm_ln_fwd_full_row_tile(ops, mnk):
+    """csmae_gemm_ln_fwd (128 x 512 tile, eight waves along N, LayerNorm in the epilogue): X = A W^T + bias + resid, Y = LN(X), mean / rstd of X
+    — against fp32 torch on the same bf16 operands AND against the two-kernel path it replaces (csmae_gemm_ks + csmae_layernorm_fwd: X bit-identical,
+    same MFMA shape and K order; Y / statistics to fp32 rounding of the different summation trees), ragged M, N < 512 (idle waves), K = 64 (one K step)."""
+    from csmae_hip import EPI_RESID
+    M, N, K = mnk
+    a = dev(rnd(M, K, seed=60).to(torch.bfloat16))
+    w = dev(rnd(N, K, seed=61, scale=K ** -0.5).to(torch.bfloat16))
+    bias, g, b = dev(rnd(N, seed=62) * 0.1), dev(rnd(N, seed=63) * 0.2 + 1.0), dev(rnd(N, seed=64) * 0.1)
+    resid = dev((rnd(M, N, seed=65, scale=2.0) + 0.5).to(torch.bfloat16))
+    wk = _kslab_torch(w)
+    x = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    mean, rstd = torch.full((M,), float("nan"), device="cuda"), torch.full((M,), float("nan"), device="cuda")
+    assert ops.gemm_ln_supported(M, N, K)
+    ops.gemm_ln_fwd(a, wk, bias, resid, x, g, b, y, mean, rstd)
+    ref_x = a.float() @ w.float().t() + bias + resid.float()
+    assert_close(x, ref_x, 1e-2, 1e-2, f"gemm_ln_fwd x {mnk}")
+    xr = x.float()
+    assert_close(mean, xr.mean(1), 1e-5, 1e-5, "gemm_ln_fwd mean")
+    assert_close(rstd, (xr.var(1, unbiased=False) + 1e-6).rsqrt(), 1e-5, 1e-6, "gemm_ln_fwd rstd")
+    assert_close(y, torch.nn.functional.layer_norm(xr, (N,), g, b, 1e-6), 1e-2, 1e-2, "gemm_ln_fwd y")
+    # the two kernels it replaces
+    x2, y2 = torch.empty_like(x), torch.empty_like(y)
+    m2, r2 = torch.empty_like(mean), torch.empty_like(rstd)
+    ops.gemm(a, w, x2, bias=bias, epilogue=EPI_RESID, resid=resid)
+    ops.layernorm_fwd(x2, g, b, y2, m2, r2)
+    assert torch.equal(x, x2), "the fused product differs from csmae_gemm's"
+    assert_close(mean, m2, 1e-5, 1e-5, "mean vs ln_fwd"); assert_close(rstd, r2, 1e-5, 1e-6, "rstd vs ln_fwd")
+    assert float((y.float() - y2.float()).abs().max()) <= 2.0 ** -6 * float(y2.float().abs().max()), "y vs ln_fwd: more than one bf16 step apart"
+    # deterministic
+    x3, y3 = torch.empty_like(x), torch.empty_like(y)
+    ops.gemm_ln_fwd(a, wk, bias, resid, x3, g, b, y3, m2, r2)
+    assert torch.equal(x, x3) and torch.equal(y, y3) and torch.equal(mean, m2) and torch.equal(rstd, r2)
+
+
+@pytest.mark.parametrize("mnk", LN_GEMM_SHAPES)
+@pytest.mark.parametrize("with_dres", [True, False])
+def test_gemm_ln_bwd_full_row_tile(ops, mnk, with_dres):
+    """csmae_gemm_ln_bwd: dx = LayerNorm'(dY W) + dres_in and the tiles' dgamma / dbeta partial rows (folded by csmae_ln_param_reduce_rows), against
+    fp32 torch autograd on the same bf16 operands and against the two-kernel path it replaces (csmae_gemm + csmae_layernorm_bwd on the rounded
+    product: same arithmetic, different summation trees)."""
+    M, N, K = mnk
+    dy = dev(rnd(M, K, seed=70).to(torch.bfloat16))
+    w = dev(rnd(K, N, seed=71, scale=K ** -0.5).to(torch.bfloat16))     # [out = K][in = N], torch's layout of the Linear behind the LayerNorm
+    x = dev((rnd(M, N, seed=72, scale=2.0) + 0.5).to(torch.bfloat16))
+    g, b = dev(rnd(N, seed=73) * 0.2 + 1.0), dev(rnd(N, seed=74) * 0.1)
+    dres = dev(rnd(M, N, seed=75).to(torch.bfloat16)) if with_dres else None
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.layernorm_fwd(x, g, b, y, mean, rstd)
+    rows = -(-M // 128)
+    part = torch.full((2, rows * 2 * N + 64), float("nan"), device="cuda")
+    dx = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_ln_bwd(dy, w, x, mean, rstd, g, dres, dx, partial_ws=part[0])
+    # reference: autograd through LayerNorm with the (bf16-rounded, as the two-kernel path rounds it) product as upstream gradient
+    t1 = (dy.float() @ w.float()).to(torch.bfloat16).float()
+    xr, gr, br = x.float().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (N,), gr, br, 1e-6).backward(t1)
+    want = xr.grad + (dres.float() if with_dres else 0.0)
+    assert_close(dx, want, 1e-2, 2e-2, f"gemm_ln_bwd dx {mnk}")
+    flatg = torch.zeros(2 * N, device="cuda")
+    goff = torch.tensor([[0, N]], dtype=torch.long, device="cuda")
+    ops.ln_param_reduce_rows(1, rows, N, part, goff, flatg)
+    scale = max(1.0, M ** 0.5)
+    assert_close(flatg[:N], gr.grad, 2e-2, 2e-2 * scale, "gemm_ln_bwd dgamma")
+    assert_close(flatg[N:], br.grad, 2e-2, 2e-2 * scale, "gemm_ln_bwd dbeta")
+    # the two kernels it replaces
+    t1k = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dy, w, t1k, trans_b=True)
+    dx2 = torch.empty_like(dx)
+    pw = torch.empty(1024 * 2 * N, device="cuda")
+    dg2, db2 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    ops.layernorm_bwd(t1k, x, mean, rstd, g, dx2, dg2, db2, dres_in=dres, partial_ws=pw)
+    d = (dx.float() - dx2.float()).abs()
+    assert float(d.max()) <= 2.0 ** -6 * float(dx2.float().abs().max()) + 1e-6, f"dx vs gemm + ln_bwd: {float(d.max())}"
+    assert_close(flatg[:N], dg2, 1e-3, 1e-3 * scale, "dgamma vs ln_bwd"); assert_close(flatg[N:], db2, 1e-3, 1e-3 * scale, "dbeta vs ln_bwd")
+    # deterministic (fixed summation order across the eight waves and the tiles)
+    dx3 = torch.empty_like(dx)
+    ops.gemm_ln_bwd(dy, w, x, mean, rstd, g, dres, dx3, partial_ws=part[1])
+    assert torch.equal(dx, dx3) and torch.equal(part[0][: rows * 2 * N], part[1][: rows * 2 * N])
+
+
+def test_gemm_ln_rejects_shapes_it_cannot_hold(ops):
+    import csmae_hip
+    assert not ops.gemm_ln_supported(128, 768, 768) and not ops.gemm_ln_supported(128, 512, 96) and not ops.gemm_ln_supported(128, 520, 64)
+    a = torch.zeros(128, 768, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(csmae_hip.CsmaeError, match="N <= 512"):
+        ops.gemm_ln_bwd(a, torch.zeros(768, 768, device="cuda", dtype=torch.bfloat16), a, torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda"),
+                        torch.ones(768, device="cuda"), None, torch.empty_like(a))
+
+
 def test_gemm_residual_epilogue_bf16_stream(ops):
     """C = A W^T + bias + resid with the residual stream in bf16 (C and resid share a dtype), on the pipelined-kernel shapes
     (256-row / 192-row tiles) and a small one; reference in fp32 on the same bf16 operands."""
