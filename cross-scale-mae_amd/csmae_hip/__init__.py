@@ -33,6 +33,7 @@ _SIGNATURES = {
     "csmae_gemm_dw_mode": [I],
     "csmae_gemm_dw": [I, L, L, L, P, L, P, L, P, P, P, L, P],
     "csmae_gemm_dw_group": [I, I, L, P, P, P, P, P, P, P, P, I, P, L, P],
+    "csmae_gemm_dw_group_fp8": [I, L, P, P, P, P, P, P, P, P, P, P, I, P, L, P],
     "csmae_fp8_amax": [I, L, I, P, L, P, P],
     "csmae_fp8_quantize": [I, I, I, L, I, P, L, P, L, P, P, P, P],
     "csmae_fp8_weights": [I, P, P, P, P, P, P, P],

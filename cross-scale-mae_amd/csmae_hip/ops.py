@@ -293,6 +293,36 @@ class DwGroup:
             _timer.end(("gemm_bf16" if self.dtype == BF16 else "gemm_f32") + "_TN", self.flops)
 
 
+class DwGroup8:
+    """Argument block of one grouped fp8 weight-gradient launch (csmae_gemm_dw_group_fp8): products [(dy8 [K, >=M] uint8 e5m2, dq_y [1], x8 [K, >=N] uint8 e4m3,
+    dq_x [1], dw [M, N] fp32 contiguous, db [M] fp32 or None)] over one K."""
+
+    def __init__(self, products, workspace):
+        n = len(products)
+        self.K = products[0][0].shape[0]
+        self.keep = (products, workspace)
+        for dy, dqy, x, dqx, dw, db in products:
+            assert dy.dtype == x.dtype == torch.uint8 and dy.shape[0] == x.shape[0] == self.K and dy.stride(1) == x.stride(1) == 1 and dw.is_contiguous()
+            assert dqy.dtype == dqx.dtype == torch.float32 and dqy.numel() >= 1 and dqx.numel() >= 1
+        VP, LL = ctypes.c_void_p * n, ctypes.c_longlong * n
+        self.n = n
+        self.dY, self.X = VP(*[_p(q[0]) for q in products]), VP(*[_p(q[2]) for q in products])
+        self.dqy, self.dqx = VP(*[_p(q[1]) for q in products]), VP(*[_p(q[3]) for q in products])
+        self.dW, self.dB = VP(*[_p(q[4]) for q in products]), VP(*[_p(q[5]) for q in products])
+        self.ldy, self.ldx = LL(*[q[0].stride(0) for q in products]), LL(*[q[2].stride(0) for q in products])
+        self.M, self.N = LL(*[q[4].shape[0] for q in products]), LL(*[q[4].shape[1] for q in products])
+        self.flops = sum(2.0 * q[4].shape[0] * q[4].shape[1] * self.K for q in products)
+        self.ws, self.ws_n = _p(workspace), workspace.numel()
+
+    def launch(self, slots=0, st=None):
+        if _timer is not None:
+            _timer.begin()
+        check(load().csmae_gemm_dw_group_fp8(self.n, self.K, self.dY, self.ldy, self.dqy, self.X, self.ldx, self.dqx, self.dW, self.dB, self.M, self.N, slots,
+                                             self.ws, self.ws_n, st if st is not None else stream()), "csmae_gemm_dw_group_fp8")
+        if _timer is not None:
+            _timer.end("gemm_fp8_TN", self.flops)
+
+
 def attn_resident(dtype_code, T, hd):
     """True when (dtype, T, head_dim) runs the LDS-resident MFMA attention kernels (the ones that can emit an fp8 copy of their output)."""
     return load().csmae_attn_resident(dtype_code, T, hd) == 1

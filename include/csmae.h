@@ -99,6 +99,14 @@ int csmae_gemm_dw(int dtype, long long M, long long N, long long K, const void* 
 int csmae_gemm_dw_group(int dtype, int count, long long K, const void* const* dY, const long long* ldy, const void* const* X,
                         const long long* ldx, float* const* dW, float* const* db, const long long* M, const long long* N, int slots,
                         float* workspace, long long ws_elems, void* stream);
+/* The same grouped weight gradients with fp8 operands (ABI version 7; BASELINE.json configs[4]; csrc/gemm_fp8_dw.hip): dW[i] += dq_y[i] dq_x[i] dY8[i]^T X8[i],
+ * db[i] (nullable) += dq_y[i] colsum(dY8[i]); dY8 e5m2 bytes [K][ldy] (the gradient copies the dX products read), X8 e4m3 bytes [K][ldx] (the activation
+ * copies the forward products read), dq_* device scalars (the de-quantisation factors their producers left), fp32 accumulation on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with both operands K-strided (ds_read_b64_tr_b8).  M, N >= 256, N % 4 == 0, ld % 16 == 0.  Workspace as csmae_gemm_dw_group
+ * plus count * 64 * roundup(max M, 256) floats for the bias-gradient partial sums.  Fixed summation order.  timm Block backward: MAE_ViT_Baseline.py:160-188. */
+int csmae_gemm_dw_group_fp8(int count, long long K, const void* const* dY, const long long* ldy, const float* const* dq_y, const void* const* X,
+                            const long long* ldx, const float* const* dq_x, float* const* dW, float* const* db, const long long* M, const long long* N,
+                            int slots, float* workspace, long long ws_elems, void* stream);
 /* ---- fp8 MFMA path (BASELINE.json configs[4]: "fp8 MFMA GEMMs"; the same nn.Linear call sites, MAE_ViT_Baseline.py:160-188).
  * OCP fp8, per-tensor scales.  An amax is 64 partial maxima (float[64]; its value is their maximum: thousands of same-address atomics per
  * launch serialise in L2): csmae_fp8_amax folds max|x| into slots the caller zeroed; csmae_fp8_quantize writes

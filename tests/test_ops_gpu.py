@@ -150,6 +150,37 @@ def test_gemm_dw_group_two_workgroups_per_cu_kernel(ops, case):
         lib.csmae_gemm_dw_mode(0)
 
 
+@pytest.mark.parametrize("case", [(512, [(256, 256)], 4, 0), (1000, [(256, 512), (520, 264)], 16, 16), (4096, [(768, 768), (2304, 768)], 160, 0), (640, [(1280, 1280), (1280, 5120)], 256, 0),
+                                  (131, [(256, 256)], 1, 0)])
+def test_gemm_dw_group_fp8(ops, case):
+    """csmae_gemm_dw_group_fp8: dW += dq_y dq_x dY8^T X8 and db += dq_y colsum(dY8) with both operands K-strided fp8 bytes (dY e5m2, X e4m3), against fp32
+    torch on the SAME fp8 values (the kernel's only error is fp32 accumulation order), one and several K slices, ragged sizes, padded rows, a K that is
+    not a multiple of the 128-token step; deterministic."""
+    K, prods, slots, pad = case
+    ws = torch.empty(64 << 20, device="cuda")
+    items = []
+    for i, (M, N) in enumerate(prods):
+        pm, pn = (pad + (-(M + pad)) % 16, pad + (-(N + pad)) % 16) if pad else ((-M) % 16, (-N) % 16)   # rows are 16-byte multiples
+        dy = rnd(K, M + pm, seed=320 + i) * 3.0
+        x = rnd(K, N + pn, seed=330 + i)
+        dy8 = dev(dy).to(torch.float8_e5m2)
+        x8 = dev(x).to(torch.float8_e4m3fn)
+        dqy, dqx = torch.tensor([0.37 + 0.1 * i], device="cuda"), torch.tensor([1.7], device="cuda")
+        items.append((dy8, dqy, x8, dqx, M, N))
+    runs = []
+    for _ in range(2):
+        outs = [(torch.full((M, N), 0.25, device="cuda"), torch.full((M,), 0.25, device="cuda")) for *_, M, N in items]
+        ops.DwGroup8([(dy8.view(torch.uint8)[:, :M], dqy, x8.view(torch.uint8)[:, :N], dqx, dw, db) for (dy8, dqy, x8, dqx, M, N), (dw, db) in zip(items, outs)], ws).launch(slots)
+        runs.append(outs)
+    for (dy8, dqy, x8, dqx, M, N), (dw, db), (dw2, db2) in zip(items, runs[0], runs[1]):
+        assert torch.equal(dw, dw2) and torch.equal(db, db2), "fp8 weight-gradient fold is not deterministic"
+        a, b = dy8.float()[:, :M], x8.float()[:, :N]
+        want = 0.25 + float(dqy) * float(dqx) * (a.double().t() @ b.double()).float()
+        assert_close(dw, want, 1e-4, 1e-4 * float(want.abs().max()), f"fp8 dW {M}x{N} K={K}")
+        wantb = 0.25 + float(dqy) * a.double().sum(0).float()
+        assert_close(db, wantb, 1e-4, 1e-4 * float(wantb.abs().max()), f"fp8 db {M} K={K}")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("slots", [4, 40, 160])
 def test_gemm_dw_group(ops, dtype, slots):
