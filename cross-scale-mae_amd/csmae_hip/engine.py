@@ -148,6 +148,10 @@ class Workspace:
             return d
         self.enc = stack(c["Ne"], Me, D, c["He"])
         self.dec = stack(c["Nd"], Md, Dd, c["Hd"])
+        if eng.fp8 and eng.fp8_dw:   # fp8 weight gradients: the fp8 copies of y1 / o / y2 / h that the forward products read are KEPT per layer (they are the dW products' X operands)
+            u8 = dict(device=dev, dtype=torch.uint8)
+            for S, nl, M, Dm in ((self.enc, c["Ne"], Me, D), (self.dec, c["Nd"], Md, Dd)):
+                S.update(y1_8=E(nl, M, Dm, **u8), o_8=E(nl, M, Dm, **u8), y2_8=E(nl, M, Dm, **u8), h_8=E(nl, M, 4 * Dm, **u8))
         self.lat_lp = E(Me, D, **lp) if (T != torch.float32 and eng.res_dtype == torch.float32) else None
         self.lat32 = E(Me, D, **f32) if eng.res_dtype != torch.float32 else None   # fp32 copy of the latent for the loss heads / outputs
         self.z = E(Me, Dd, **f32)
@@ -217,6 +221,12 @@ class Workspace:
             self.q_b = [E(big8, device=dev, dtype=torch.uint8) for _ in range(2)]   # fp8 copies emitted by the fc1 / fc2-backward epilogues (h, dpre)
             self.q_a = [E(big8 // 4, device=dev, dtype=torch.uint8) for _ in range(2)]  # ... by LayerNorm forward (y1, y2) / backward (the residual gradient)
             self.fp8_dq = torch.ones(nsite, **f32)
+            if eng.fp8_dw:   # fp8 twins of the rotating gradient buffers (dpre, dqkv, the five residual-gradient buffers per stack): the dW products' dY operands
+                u8 = dict(device=dev, dtype=torch.uint8)
+                self.t4_8 = [E(big8, **u8) for _ in range(2)]
+                self.t3_8 = [E(max(Me * 3 * D, Md * 3 * Dd), **u8) for _ in range(2)]
+                self.dres_e_8 = [E(Me, D, **u8) for _ in range(5)]
+                self.dres_d_8 = [E(Md, Dd, **u8) for _ in range(5)]
             self.fp8_hist = False    # the previous step's amax exist (delayed scaling from the second step on)
             self.fp8_complete = False
         self.dw_ws = E(64 * 1024 * 1024, **f32)  # K-slice slabs of the weight-gradient launches (256 MiB)
@@ -229,6 +239,9 @@ class Engine:
         # (per-tensor scaled OCP fp8 operands: activations / weights e4m3, gradients e5m2; fp32 accumulation; weight gradients stay bf16)
         self.fp8 = act_dtype == "fp8"
         self._fp8_site = 0
+        self.fp8_dw = self.fp8 and not debug_opt("fp8_bf16_dw")   # weight gradients on the fp8 MFMA path too (csmae_gemm_dw_group_fp8); A/B aid: bf16 weight gradients
+        self._fp8_blk = {}      # (stack, block) -> the block's forward GEMM sites (y1, o, y2, h): shared by the two views' calls, read by the backward pass
+        self._fp8_kept = {}     # (stack, block) -> which kept fp8 copies (y1_8 / o_8 / y2_8 / h_8) the last forward wrote
         self._fp8_cur = None    # (site, fp8 bytes or None) of the residual gradient the next block's fc2-backward product reads
         self._fp8_fuse_lnb = not debug_opt("fp8_no_fuse_lnb")
         self._fp8_fuse_attn = not debug_opt("fp8_no_fuse_attn")   # A/B aid: attention's fp8 copies by separate quantisation passes
@@ -407,6 +420,7 @@ class Engine:
             ws.fp8_complete = False
             ws.fp8_amax[0].zero_()
             self._fp8_site = 0
+            self._fp8_blk, self._fp8_kept = {}, {}
 
     def _fp8_alloc(self):
         """Next GEMM-site index of the step (None outside fp8 mode).  The order of the calls is the same every step: that is what ties
@@ -425,7 +439,14 @@ class Engine:
             return None
         return (buf[: M * N].view(M, N), fmt, ws.fp8_amax[1][site], ws.fp8_amax[0][site], ws.fp8_dq[site:site + 1])
 
-    def _mm(self, a, name, out, *, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None, lane=0, site=None, emit_site=None, a8=None):
+    def _emit_to(self, site, dst, fmt):
+        """_emit with the destination given as a [M, N] uint8 view (a kept per-layer copy / a rotating twin) instead of a staging buffer."""
+        ws = self.ws
+        if site is None or not self.fp8 or not ws.fp8_hist or not self._fp8_fuse:
+            return None
+        return (dst, fmt, ws.fp8_amax[1][site], ws.fp8_amax[0][site], ws.fp8_dq[site:site + 1])
+
+    def _mm(self, a, name, out, *, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None, lane=0, site=None, emit_site=None, a8=None, emit_dst=None):
         """out = a W^T (forward) / a W (trans_b: dX) for a block weight `name`, through the bf16 / fp32 GEMM or, in fp8 mode, through
         quantise(a) + the fp8 GEMM.  `lane` picks the fp8 staging buffers (the two forward streams quantise concurrently).
         `emit_site`: this product's output is the A operand of GEMM site `emit_site` — with delayed scaling the epilogue writes its fp8
@@ -452,7 +473,8 @@ class Engine:
                 ops.fp8_quantize(a, a8, prev[k], ws.fp8_dq[k:k + 1], fmt=fmt, amax_next=cur[k], st=st)
             else:
                 ops.fp8_quantize(a, a8, cur[k], ws.fp8_dq[k:k + 1], fmt=fmt, st=st)
-        emit = self._emit(emit_site, ws.q_b[lane], out.shape[0], out.shape[1], fmt)   # (a forward product feeds a forward product, a dX product a dX product)
+        # (a forward product feeds a forward product, a dX product a dX product; emit_dst: the copy's home when it is kept for the weight gradients)
+        emit = self._emit_to(emit_site, emit_dst, fmt) if emit_dst is not None else self._emit(emit_site, ws.q_b[lane], out.shape[0], out.shape[1], fmt)
         wi = f.w8_idx[name]
         return ops.gemm_fp8(a8, b8, out, ws.fp8_dq[k:k + 1], f.w8_dq[wi:wi + 1], a_fmt=fmt, bias=bias, epilogue=epilogue, aux=aux, resid=resid,
                             emit=emit, st=st)
@@ -468,14 +490,25 @@ class Engine:
         """dW[name] += dy^T x ; db[name] += colsum(dy)   (dy [tokens, >=out], x [tokens, >=in]; extra pad columns ignored)."""
         self._dw_group([(dy, x, name)])
 
-    def _dw_group(self, items, slots=None, ready=None):
+    def _dw_group(self, items, slots=None, ready=None, items8=None):
         """Weight gradients of several Linear layers over the same tokens, [(dy, x, name)], in one launch (csmae_gemm_dw_group: the
         products share the chip, K slices are folded inside the kernel, the result goes straight into the gradient buffer).
 
         Weight gradients are leaves of the backward graph, so they run on a second HIP stream: their workgroups fill the CUs that the
         main chain's tails, small GEMMs, LayerNorm and attention kernels leave idle."""
-        key = tuple((n, dy.data_ptr(), x.data_ptr()) for dy, x, n in items)
-        grp = self._dw_cache.get(key)
+        if items8 is not None:   # the same products from the fp8 copies of their operands: [(dy8, dq_y, x8, dq_x, name)] (csmae_gemm_dw_group_fp8)
+            key = tuple((n, dy.data_ptr(), x.data_ptr(), qy.data_ptr(), qx.data_ptr()) for dy, qy, x, qx, n in items8)
+            grp = self._dw_cache.get(key)
+            if grp is None:
+                prods = []
+                for dy, qy, x, qx, name in items8:
+                    gw = self.flat.G(name + ".weight")
+                    gw2 = gw.view(gw.shape[0], -1)
+                    prods.append((dy[:, : gw2.shape[0]], qy, x[:, : gw2.shape[1]], qx, gw2, self.flat.G(name + ".bias")))
+                grp = self._dw_cache[key] = ops.DwGroup8(prods, self.ws.dw_ws)
+        else:
+            key = tuple((n, dy.data_ptr(), x.data_ptr()) for dy, x, n in items)
+            grp = self._dw_cache.get(key)
         if grp is None:
             prods = []
             for dy, x, name in items:
@@ -551,17 +584,25 @@ class Engine:
         ws_q_a = self.ws.q_a if self.fp8 else None
         ln = int(b0 > 0)
         Mr = y1.shape[0]
-        k1 = self._fp8_alloc()
-        e1 = self._emit(k1, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
+        k1 = ko = k2 = kh = None
+        if self.fp8:
+            # The block's four forward GEMM sites (A operands y1, o, y2, h) are shared by the two views' calls: one scale per tensor over the whole batch
+            # — the weight gradients contract over both views' tokens at once.  (The step without amax history quantises with the tensor's own maximum,
+            # which two concurrent calls cannot share: that step runs un-split, see _forward.)
+            sites = self._fp8_blk.get((id(S), i))
+            if sites is None:
+                sites = self._fp8_blk[(id(S), i)] = tuple(self._fp8_alloc() for _ in range(4))
+            k1, ko, k2, kh = sites
+        keep8 = self.fp8 and self.fp8_dw   # the fp8 copies go to their per-layer homes (the dW products read them in the backward pass) instead of a staging buffer
+        d8 = (lambda name, stage, n: S[name][i][r] if keep8 else stage[: Mr * n].view(Mr, n))
+        e1 = self._emit_to(k1, d8("y1_8", ws_q_a[ln], Dm), 0) if self.fp8 else None
         fuse = self._ln_fused_fwd(Mr, Dm)
         if not (fuse and i > 0):   # (fused: the previous block's fc2 epilogue has already left norm1(x_in) in y1 and its statistics)
             ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, st=st)
         self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=ln, site=k1, a8=e1[0] if e1 else None)
         # (fp8 mode) attention leaves its output as fp8 bytes for attn.proj (q_a: y1 has been consumed by the qkv GEMM, y2 comes after proj)
-        ko = self._fp8_alloc()
-        eo = self._emit(ko, ws_q_a[ln], Mr, Dm, 0) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
+        eo = self._emit_to(ko, d8("o_8", ws_q_a[ln], Dm), 0) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
         ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, emit=eo, st=st)
-        k2 = None
         if fuse:   # x_mid = x_in + proj(o) and y2 = norm2(x_mid) in one kernel
             ops.gemm_ln_fwd(o, self._ks(pre + "attn.proj.weight"), P(pre + "attn.proj.bias"), x_in, x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"),
                             y2, stt[2], stt[3], st=st)
@@ -569,12 +610,15 @@ class Engine:
         else:
             self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0), site=ko,
                      a8=eo[0] if eo else None)
-            k2 = self._fp8_alloc()
-            e2 = self._emit(k2, ws_q_a[ln], Mr, Dm, 0) if self.fp8 else None
+            e2 = self._emit_to(k2, d8("y2_8", ws_q_a[ln], Dm), 0) if self.fp8 else None
             ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], emit=e2, st=st)
-        kh = self._fp8_alloc()   # (fp8 mode) the site of fc2's A operand: h leaves the fc1 epilogue as bf16 AND as fp8 bytes
-        eh = self._emit(kh, self.ws.q_b[ln], Mr, 4 * Dm, 0) if self.fp8 else None
-        self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=ln, site=k2, a8=e2[0] if e2 else None, emit_site=kh)
+        # (fp8 mode) kh = the site of fc2's A operand: h leaves the fc1 epilogue as bf16 AND as fp8 bytes
+        h8 = d8("h_8", self.ws.q_b[ln], 4 * Dm) if self.fp8 else None
+        eh = self._emit_to(kh, h8, 0) if self.fp8 else None
+        self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=ln, site=k2, a8=e2[0] if e2 else None, emit_site=kh,
+                 emit_dst=h8)
+        if keep8:   # which of the block's kept copies this pass really wrote (none without amax history; o only from the LDS-resident attention kernels)
+            self._fp8_kept[(id(S), i)] = dict(y1=e1 is not None, o=eo is not None, y2=e2 is not None, h=eh is not None)
         if fuse and i + 1 < S["xm"].shape[0]:   # x_out = x_mid + fc2(h) and the NEXT block's y1 = norm1(x_out) in one kernel
             nxt = pre[: pre.rstrip(".").rfind(".") + 1] + f"{i + 1}."
             sn = [a[r] for a in S["st"][i + 1][:2]]
@@ -593,7 +637,7 @@ class Engine:
     def _ln_fused_bwd(self, M, Dm):
         return self.ln_fuse_bwd and ops.gemm_ln_supported(M, Dm, 4 * Dm)
 
-    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, k, part):
+    def _block_bwd(self, S, i, pre, M, Dm, H, B2, T, dres, lps, k, part, lps8=None):
         """`lps` = the rotating low-precision copies of the residual gradient, lps[k] is current on entry; returns the index that is
         current on exit.  With a bf16 residual stream they ARE the residual gradient (`dres` is None); with the fp32 stream `dres` is
         updated in place.  `part` = partial-row slices of this block's two LayerNorms (norm1, norm2): their dgamma / dbeta are folded
@@ -633,16 +677,27 @@ class Engine:
         kc, c8 = self._fp8_cur if self._fp8_cur is not None else (None, None)
         self._fp8_cur = None
         kd = self._fp8_alloc()
-        ed = self._emit(kd, ws.q_b[0], M, 4 * Dm, 1) if self.fp8 else None
+        # fp8 weight gradients: the fp8 copies of the gradient tensors live in twins of the rotating bf16 buffers (same indices, same lifetimes: the guards
+        # on the bf16 buffers cover them) instead of two staging buffers that the next kernel of the chain overwrites
+        tw = self.fp8 and self.fp8_dw and lps8 is not None
+        dpre8 = ws.t4_8[self._tog][: M * 4 * Dm].view(M, 4 * Dm) if tw else None
+        ed = (self._emit_to(kd, dpre8, 1) if tw else self._emit(kd, ws.q_b[0], M, 4 * Dm, 1)) if self.fp8 else None
         # the kernels whose outputs a weight-gradient launch waits for carry that launch's event themselves (an event recorded behind them
         # is a marker packet: ~5 us of idle main stream each, two per block)
         carried = ops._timer is None and not os.environ.get("CSMAE_DW_MAIN")
         ev1 = self._event() if (carried and mode == "half") else None
         with (ops.launch_done(ev1, st) if ev1 is not None else contextlib.nullcontext()):
-            self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd)
+            self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd, emit_dst=dpre8)
         slots = self._dw_slots_ed[0 if S is ws.enc else 1] if self._dw_slots_ed else None
+        kept = self._fp8_kept.get((id(S), i), {}) if tw else {}
+        fs = self._fp8_blk.get((id(S), i)) if tw else None   # the block's forward sites (y1, o, y2, h)
+        dq = ws.fp8_dq if self.fp8 else None
+        ok8 = tw and fs is not None and Dm >= 256 and Dm % 16 == 0
         if mode == "half":
-            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, ready=ev1)
+            g8 = None
+            if ok8 and c8 is not None and ed is not None and kept.get("h") and kept.get("y2"):
+                g8 = [(c8, dq[kc:kc + 1], S["h_8"][i], dq[fs[3]:fs[3] + 1], pre + "mlp.fc2"), (ed[0], dq[kd:kd + 1], S["y2_8"][i], dq[fs[2]:fs[2] + 1], pre + "mlp.fc1")]
+            self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, ready=ev1, items8=g8)
         elif mode == "none":
             self._dw(dpre, y2, pre + "mlp.fc1")
         fuse = dres is None and self._ln_fused_bwd(M, Dm)
@@ -654,7 +709,9 @@ class Engine:
             self._mm(dpre, pre + "mlp.fc1.weight", t1, trans_b=True, st=st, site=kd, a8=ed[0] if ed else None)
             self._guard_write(nxt)
             kn = self._fp8_alloc()
-            en = self._emit(kn, ws.q_a[0], M, Dm, 1) if (self.fp8 and self._fp8_fuse_lnb) else None
+            en = None
+            if self.fp8 and self._fp8_fuse_lnb:
+                en = self._emit_to(kn, lps8[(k + 1) % n], 1) if tw else self._emit(kn, ws.q_a[0], M, Dm, 1)
         if fuse:
             pass
         elif dres is None:
@@ -669,14 +726,19 @@ class Engine:
         ev2 = self._event() if (carried and mode in ("half", "block")) else None
         # (fp8 mode) ... and dqkv for attn.qkv's backward (q_b[0]: dpre's copy has been consumed by fc1's backward GEMM)
         kq = self._fp8_alloc()
-        eq = self._emit(kq, ws.q_b[0], M, 3 * Dm, 1) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
+        eq = None
+        if self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H):
+            eq = self._emit_to(kq, ws.t3_8[self._tog][: M * 3 * Dm].view(M, 3 * Dm), 1) if tw else self._emit(kq, ws.q_b[0], M, 3 * Dm, 1)
         with (ops.launch_done(ev2, st) if ev2 is not None else contextlib.nullcontext()):
             ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, emit=eq, st=st)
         if mode == "block":
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1"),
                             (nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2)
         elif mode == "half":
-            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2)
+            g8 = None
+            if ok8 and en is not None and eq is not None and kept.get("o") and kept.get("y1"):
+                g8 = [(en[0], dq[kn:kn + 1], S["o_8"][i], dq[fs[1]:fs[1] + 1], pre + "attn.proj"), (eq[0], dq[kq:kq + 1], S["y1_8"][i], dq[fs[0]:fs[0] + 1], pre + "attn.qkv")]
+            self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2, items8=g8)
         else:
             self._dw(dqkv, y1, pre + "attn.qkv")
         if fuse:   # qkv's dX product + norm1's backward + the residual-gradient add
@@ -686,7 +748,9 @@ class Engine:
         self._mm(dqkv, pre + "attn.qkv.weight", t1, trans_b=True, st=st, site=kq, a8=eq[0] if eq else None)
         self._guard_write(out)
         kx = self._fp8_alloc() if i > 0 else None     # the next block's fc2-backward reads `out`
-        ex = self._emit(kx, ws.q_a[1], M, Dm, 1) if (self.fp8 and dres is None and self._fp8_fuse_lnb) else None
+        ex = None
+        if self.fp8 and dres is None and self._fp8_fuse_lnb:
+            ex = self._emit_to(kx, lps8[(k + 2) % n if rot else k], 1) if tw else self._emit(kx, ws.q_a[1], M, Dm, 1)
         if dres is None:
             ops.layernorm_bwd(t1, S["x"][i], stt[0], stt[1], P(pre + "norm1.weight"), out, None, None, dres_in=nxt, partial_ws=part[0], emit=ex, st=st)
         else:
@@ -729,6 +793,8 @@ class Engine:
         self._fp8_begin()
         img0 = imgs
         two = self.views == 2 and ops._timer is None and not os.environ.get("CSMAE_FWD_ONE_STREAM")
+        if self.fp8 and not ws.fp8_hist:
+            two = False   # (fp8, no amax history yet: every tensor is scaled with its own maximum over BOTH views — one call per block, see _block_fwd)
         nch = 2   # sample chunks in flight on their own streams: one per view (4 / 8 chunks and an uneven split were measured and lost)
         # (The stem per view on the view's stream — the original's patches not waiting for the crop kernel — measured neutral: 21.87 vs 21.88 ms,
         # the original's patch-embed product queues behind the crop kernel's 10 k workgroups for CUs anyway.  One stem on the main stream.)
@@ -1100,7 +1166,9 @@ class Engine:
         self._fp8_cur = None
         if lp_stream:
             k0 = self._fp8_alloc()
-            e0 = self._emit(k0, ws.q_a[1], ws.Md, Dd, 1) if (self.fp8 and self._fp8_fuse_lnb) else None
+            e0 = None
+            if self.fp8 and self._fp8_fuse_lnb:
+                e0 = self._emit_to(k0, ws.dres_d_8[0], 1) if self.fp8_dw else self._emit(k0, ws.q_a[1], ws.Md, Dd, 1)
             ops.layernorm_bwd(ws.demb, ws.dec["x"][c["Nd"]], ws.dn_st[0], ws.dn_st[1], P("decoder_norm.weight"), ws.dres_d_lp[0], None, None,
                               partial_ws=pd[Nd2], emit=e0, st=st)
             if k0 is not None:
@@ -1110,7 +1178,8 @@ class Engine:
                               dx_lp=ws.dres_d_lp[0], partial_ws=pd[Nd2], st=st)
         kd_ = 0
         for i in reversed(range(c["Nd"])):
-            kd_ = self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp, kd_, (pd[2 * i], pd[2 * i + 1]))
+            kd_ = self._block_bwd(ws.dec, i, f"decoder.{i}.", ws.Md, Dd, c["Hd"], B2, Td, ws.dres_d, ws.dres_d_lp, kd_, (pd[2 * i], pd[2 * i + 1]),
+                                  lps8=ws.dres_d_8 if (self.fp8 and self.fp8_dw and lp_stream) else None)
         if lp_stream and self._ln_fused_bwd(ws.Md, Dd):   # the blocks' LayerNorms left one partial row per GEMM tile, decoder_norm's kernel its own count
             self._ln_flush(pd, self._goff_d, 0, Nd2, ws.Md, Dd, fused=True)
             self._ln_flush(pd, self._goff_d, Nd2, Nd2 + 1, ws.Md, Dd)
@@ -1141,7 +1210,8 @@ class Engine:
         fe = lp_stream and self._ln_fused_bwd(ws.Me, D)
         ke_ = 0
         for i in reversed(range(c["Ne"])):
-            ke_ = self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, None if lp_stream else ws.dres_e, ws.dres_e_lp, ke_, (pe[2 * i], pe[2 * i + 1]))
+            ke_ = self._block_bwd(ws.enc, i, f"encoder.{i}.", ws.Me, D, c["He"], B2, Te, None if lp_stream else ws.dres_e, ws.dres_e_lp, ke_, (pe[2 * i], pe[2 * i + 1]),
+                                  lps8=ws.dres_e_8 if (self.fp8 and self.fp8_dw and lp_stream) else None)
             if dp is not None and dp.wants(("enc", i)):
                 self._ln_flush(pe, self._goff_e, 2 * i, 2 * flushed, ws.Me, D, fused=fe)   # the bucket's LayerNorm gradients must be final before its exchange
                 flushed = i
