@@ -60,6 +60,7 @@ _SIGNATURES = {
     "csmae_rows_gather": [I, L, I, P, L, L, L, P, P],
     "csmae_rows_scatter_add": [I, L, I, P, F, L, L, L, P, P],
     "csmae_rows_scatter_add2": [I, L, I, P, F, L, P, F, L, L, L, P, P],
+    "csmae_spec_fixup": [P, P, L, P, L, P, L, P, P, P, P, I, P],
     "csmae_rows_gather_idx": [L, I, I, I, P, P, L, P, P],
     "csmae_target_minmax": [I, L, I, I, I, I, P, P, P, P, P],
     "csmae_recon_loss_fwd": [I, I, I, L, I, I, I, I, P, P, P, L, P, P, P, P],

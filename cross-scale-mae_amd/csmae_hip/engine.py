@@ -181,6 +181,8 @@ class Workspace:
             self.dv = E(N * L, Dd, **lp)
             self.dr = E(N * L, Hp, **lp)
             self.dpin = E(N * L, Dd, **lp)
+            self.bn_tmp = torch.zeros(2, L, **f32)   # BatchNorm's dgamma / dbeta of the speculative (unit-gradient) backward chain
+            self.one = torch.ones(1, **f32)
         if eng.has_ce:
             self.zc = E(B2, D, **f32)
             self.inv_norm = E(B2, **f32)
@@ -770,12 +772,12 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool,
-                img1: Optional[torch.Tensor] = None):
+                img1: Optional[torch.Tensor] = None, expect_backward: bool = False):
         with trace.range_("csmae.forward"):
-            return self._forward(imgs, mask_ratio, noise, box_host, training, img1)
+            return self._forward(imgs, mask_ratio, noise, box_host, training, img1, expect_backward)
 
     def _forward(self, imgs: torch.Tensor, mask_ratio: float, noise: torch.Tensor, box_host: Optional[torch.Tensor], training: bool,
-                 img1: Optional[torch.Tensor] = None):
+                 img1: Optional[torch.Tensor] = None, expect_backward: bool = False):
         """`img1`: the second view given explicitly (MAE_ViT_MsLd_PAIRED, MAE_ViT_MsLd.py:79-146) instead of the random resized crop of `imgs`."""
         c = self.cfg
         N = imgs.shape[0]
@@ -954,13 +956,30 @@ class Engine:
             ws.rowloss.zero_()
         elif not view_heads:
             ops.recon_loss_fwd(kind, npx, img0, img1, ws.pred, mm, ws.rowloss, B2, N, c["C"], c["S"], c["p"], mask=ws.mask, st=st)
-        kw = {}
+        kw, kw_spec = {}, False
         if self.has_pred:
             kcd = c["loss_cd"]
             if not view_heads:
                 predictor_fwd(st)
             ops.pair_loss_fwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.cd_partial, st=st)
             kw.update(cd_partial=ws.cd_partial, cd_scale=self._pair_scale(kcd, N * L, Dd))
+            # The head's BACKWARD chain (pair loss -> Linear -> BatchNorm / ReLU -> Linear: ~340 us, the longest chain of the forward / backward junction)
+            # starts here, on the auxiliary stream, with unit upstream gradient: every gradient is linear in that scalar, and _backward applies the real
+            # one (csmae_spec_fixup: a no-op for 1.0).  Only for a training forward that autograd records (`expect_backward`: the model's autograd node).
+            spec = (training and expect_backward and view_heads and ops._timer is None and self.T == BF16 and not os.environ.get("CSMAE_DW_MAIN")
+                    and not debug_opt("no_spec_junction"))
+            if spec:
+                bn, aux, ast = "predictor.1.", self.aux, self.aux.cuda_stream
+                ev = torch.cuda.Event()
+                ev.record(main)
+                aux.wait_event(ev)
+                with torch.cuda.stream(aux):
+                    ws.bn_tmp.zero_()
+                ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.one, self._pair_scale(kcd, N * L, Dd), da_lp=ws.dv, st=ast)
+                ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=ast)
+                ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, ws.bn_tmp[0], ws.bn_tmp[1], N, L, st=ast)
+                ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=ast)
+            kw_spec = spec
         if self.has_le:
             ke = c["loss_e"]
             ops.pair_loss_fwd(ke, N * Te, D, lat_heads, (N * Te, 0, N * Te), lat_heads, (N * Te, 0, 0), ws.e_partial, st=st)
@@ -976,7 +995,7 @@ class Engine:
         if ssim is not None:
             ops.ssim_apply(kind == "none", self.views, ssim[2], rscale, ws.ssim_terms, ws.losses, st=st)
         self.gen += 1
-        self._saved = dict(img0=img0, img1=img1, N=N, keep=keep, mm=mm, rscale=rscale, gen=self.gen)
+        self._saved = dict(img0=img0, img1=img1, N=N, keep=keep, mm=mm, rscale=rscale, gen=self.gen, spec=bool(self.has_pred and kw_spec))
         return ws
 
     # ------------------------------------------------------------------ stand-alone halves (inference, one view)
@@ -1142,13 +1161,18 @@ class Engine:
                 # weight-gradient launches wait for events recorded on the auxiliary stream.
                 aux, ast = self.aux, self.aux.cuda_stream
                 aux.wait_event(head_start)                   # gout, and everything the forward pass left on the main stream
-                ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
-                                  da_lp=ws.dv, st=ast)
-                ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=ast)
-                if zeroed is not None:   # BatchNorm's parameter gradients go straight into the flat buffer: the chain's first writer into it waits
-                    aux.wait_event(zeroed)   # for the clear — not its head (the clear is a 117-us fill that starts with the backward pass)
-                ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=ast)
-                ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=ast)
+                if sv.get("spec"):   # the chain ran with unit gradient behind the forward pass (_forward): apply the real upstream gradient
+                    if zeroed is not None:
+                        aux.wait_event(zeroed)
+                    ops.spec_fixup(ws.gout, (ws.dv, ws.dr, ws.dpin), ws.bn_tmp, G(bn + "weight"), G(bn + "bias"), st=ast)
+                else:
+                    ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.gout, self._pair_scale(kcd, N * L, Dd),
+                                      da_lp=ws.dv, st=ast)
+                    ops.gemm(ws.dv, self.W("predictor.3.weight"), ws.dr, trans_b=True, st=ast)
+                    if zeroed is not None:   # BatchNorm's parameter gradients go straight into the flat buffer: the chain's first writer into it waits
+                        aux.wait_event(zeroed)   # for the clear — not its head (the clear is a 117-us fill that starts with the backward pass)
+                    ops.bnrelu_bwd(ws.u, ws.dr, P(bn + "weight"), P(bn + "bias"), ws.bn_st[0], ws.bn_st[1], ws.dr, G(bn + "weight"), G(bn + "bias"), N, L, st=ast)
+                    ops.gemm(ws.dr, self.W("predictor.0.weight"), ws.dpin, trans_b=True, st=ast)
                 self.main.wait_stream(aux)
                 ops.rows_scatter_add2(ws.dv, -1.0, 1, ws.dpin, 1.0, N * Td + 1, ws.demb, L, Td, st=st)
                 # the heads' weight-gradient launches wait for the junction to be over (an event behind the combining kernel): started as soon

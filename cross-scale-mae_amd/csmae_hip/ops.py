@@ -447,6 +447,14 @@ def rows_scatter_add2(a, scale_a, off_a, b, scale_b, off_b, dst, group, gstride,
                                          st if st is not None else stream()), "csmae_rows_scatter_add2")
 
 
+def spec_fixup(g, bufs, tmp, dgamma, dbeta, st=None):
+    """The speculative cross-decoder backward's fix-up (csmae.h csmae_spec_fixup): dgamma / dbeta += g * tmp[0] / tmp[1]; the three bf16 tensors *= g (no-op for g == 1)."""
+    b0, b1, b2 = bufs
+    assert all(b.dtype == torch.bfloat16 and b.is_contiguous() for b in bufs) and tmp.shape[0] == 2 and tmp.dtype == torch.float32
+    check(load().csmae_spec_fixup(_p(g), _p(b0), b0.numel(), _p(b1), b1.numel(), _p(b2), b2.numel(), _p(tmp[0]), _p(tmp[1]), _p(dgamma), _p(dbeta), tmp.shape[1],
+                                  st if st is not None else stream()), "csmae_spec_fixup")
+
+
 def rows_scatter_add(src, dst, group, gstride, off, scale=1.0, st=None):
     check(load().csmae_rows_scatter_add(dt(src), src.shape[0], src.shape[1], _p(src), scale, group, gstride, off, _p(dst),
                                         st if st is not None else stream()), "csmae_rows_scatter_add")

@@ -343,6 +343,39 @@ extern "C" int csmae_rows_scatter_add2(int dtype, long long rows, int D, const v
   else { csmae_set_error("csmae_rows_scatter_add2: bad dtype %d", dtype); return CSMAE_ERR_UNSUPPORTED; }
   return csmae_check_launch("csmae_rows_scatter_add2");
 }
+// ---- the cross-decoder head's backward, run AHEAD of loss.backward() (csmae_hip/engine.py: the predictor chain pair loss -> Linear -> BatchNorm / ReLU ->
+// Linear is the longest of the forward / backward junction and depends on the upstream gradient only through a scalar factor: every gradient is
+// linear in it).  The chain runs at the end of the forward pass with unit upstream gradient; when the real one, g, arrives this kernel (a) adds
+// g x (BatchNorm's dgamma, dbeta of the unit run) into the gradient buffer and (b) scales the chain's three bf16 gradient tensors by g in place — a
+// no-op per block when g == 1 (every `loss.backward()` without gradient accumulation).  MAE_ViT_MsLdCeCd.py:56-59, MLP.py:4-10 backward.
+__global__ __launch_bounds__(256) void spec_fixup_kernel(const float* __restrict__ g, bf16_t* b0, long long n0, bf16_t* b1, long long n1, bf16_t* b2, long long n2,
+                                                         const float* __restrict__ tg, const float* __restrict__ tb, float* __restrict__ dg, float* __restrict__ db, int L) {
+  const float s = g[0];
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < L; i += blockDim.x) { dg[i] += s * tg[i]; db[i] += s * tb[i]; }
+  if (s == 1.0f) return;
+  bf16_t* bufs[3] = {b0, b1, b2};
+  const long long cnt[3] = {n0, n1, n2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint4* p = reinterpret_cast<uint4*>(bufs[k]);
+    const long long n8 = cnt[k] >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+      uint4 v = p[i];
+      unsigned* w = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = pack2bf(__uint_as_float(w[e] << 16) * s, __uint_as_float(w[e] & 0xffff0000u) * s);
+      p[i] = v;
+    }
+  }
+}
+extern "C" int csmae_spec_fixup(const float* g, void* b0, long long n0, void* b1, long long n1, void* b2, long long n2, const float* tmp_dgamma, const float* tmp_dbeta,
+                                float* dgamma, float* dbeta, int L, void* stream) {
+  CSMAE_REQUIRE(g && b0 && b1 && b2 && tmp_dgamma && tmp_dbeta && dgamma && dbeta && L > 0 && n0 % 8 == 0 && n1 % 8 == 0 && n2 % 8 == 0 &&
+                ((((uintptr_t)b0 | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0), "csmae_spec_fixup: bf16 tensors of 8-element multiples, 16-byte aligned");
+  hipLaunchKernelGGL(spec_fixup_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, g, (bf16_t*)b0, n0, (bf16_t*)b1, n1, (bf16_t*)b2, n2, tmp_dgamma, tmp_dbeta, dgamma, dbeta, L);
+  return csmae_check_launch("csmae_spec_fixup");
+}
 extern "C" int csmae_rows_gather(int dtype, long long rows, int D, const float* src, long long group, long long gstride, long long off, void* dst, void* stream) {
   CSMAE_REQUIRE(rows > 0 && D % 4 == 0 && group > 0, "csmae_rows_gather: bad geometry");
   dim3 grid((unsigned)fmin((double)rows, 4096.0)), block(128);

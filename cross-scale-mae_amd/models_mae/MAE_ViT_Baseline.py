@@ -19,7 +19,7 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, engine, imgs, mask_ratio, noise, box, anchor, img1=None):
-        ws = engine.forward(imgs, mask_ratio, noise, box, model.training, img1=img1)
+        ws = engine.forward(imgs, mask_ratio, noise, box, model.training, img1=img1, expect_backward=True)   # (the engine may start backward work that needs no upstream gradient)
         ctx.model, ctx.engine, ctx.gen = model, engine, engine.gen
         ctx.set_materialize_grads(False)
         outs = model._outputs(engine, ws, imgs.shape[0])

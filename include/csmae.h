@@ -202,6 +202,13 @@ int csmae_rows_scatter_add(int dtype, long long rows, int D, const void* src, fl
  * crop's —, MAE_ViT_MsLdCeCd.py:56-59: `loss_cd(x_embed_orig[:, 1:], predictor(x_embed_crop[:, 1:]))`, target not detached). */
 int csmae_rows_scatter_add2(int dtype, long long rows, int D, const void* a, float scale_a, long long off_a, const void* b, float scale_b, long long off_b,
                             long long group, long long gstride, float* dst, void* stream);
+/* The cross-decoder head's backward chain run AHEAD of the upstream gradient (ABI version 7): pair loss -> predictor Linear -> BatchNorm / ReLU -> Linear
+ * depends on d(loss) only through a scalar factor, so csmae_hip runs it with unit gradient at the end of the forward pass (it is the longest chain of the
+ * forward / backward junction); when the real factor g (device scalar) arrives, this call adds g x (tmp_dgamma, tmp_dbeta) — BatchNorm's parameter
+ * gradients of the unit run — into dgamma / dbeta and scales the chain's three bf16 gradient tensors (n0 / n1 / n2 elements) by g in place: nothing to
+ * scale when g == 1.  MAE_ViT_MsLdCeCd.py:56-59 backward. */
+int csmae_spec_fixup(const float* g, void* b0, long long n0, void* b1, long long n1, void* b2, long long n2, const float* tmp_dgamma, const float* tmp_dbeta,
+                     float* dgamma, float* dbeta, int L, void* stream);
 /* MAE_ViT_Shared.py:77 (`torch.gather(x, dim=1, index=ids_keep.unsqueeze(-1).repeat(1, 1, D))` of the stand-alone random_masking):
  * out[n, k, :] = x[n, ids[n * ids_ld + k], :], x [N, L, D] fp32, ids int32 (csmae_mask_sort's ids_keep), out [N, keep, D] fp32. */
 int csmae_rows_gather_idx(long long N, int L, int keep, int D, const float* x, const int* ids, long long ids_ld, float* out, void* stream);
