@@ -79,6 +79,7 @@ _SIGNATURES = {
     "csmae_next_launch_event": [P],
     "csmae_flush_launch_event": [P],
     "csmae_adamw": [L, P, P, P, P, P, P, P, F, F, F, F, F, F, P, P, P, P, P],
+    "csmae_adamw_fp8": [L, P, F, P, P, P, P, F, F, F, F, F, F, P, P, P, P, P, P, P, P],
     "csmae_gate_accumulate": [P, P, I, P],
     "csmae_clip_grad_norm": [L, P, F, P, P, P],
     "csmae_cast_f32_to_bf16": [L, P, P, P],

@@ -329,6 +329,8 @@ class Engine:
         FlatParams because every engine of a model shares the one mirror."""
         if self.T != BF16:
             return
+        if not self.fp8:
+            self.flat.fp8_active = False
         stamp = self.flat.version_stamp()
         if stamp != self.flat.lp_stamp:
             ops.cast_bf16(self.flat.p, self.flat.w_lp)
@@ -402,11 +404,18 @@ class Engine:
             f.w8 = torch.zeros(f.total, device=self.device, dtype=torch.uint8)
             f.w8t = torch.zeros(f.total, device=self.device, dtype=torch.uint8)
             f.w8_idx = {n: k for k, n in enumerate(self._fp8_names())}
-            f.w8_amax = torch.zeros(len(f.w8_idx), ops.FP8_SLOTS, device=self.device)
+            # [0]: the weights' maxima as last measured (what the mirrors' NEXT rewrite scales with), [1]: the slot FusedAdamW folds the new maxima into
+            f.w8_amax = [torch.zeros(len(f.w8_idx), ops.FP8_SLOTS, device=self.device) for _ in range(2)]
             f.w8_dq = torch.ones(len(f.w8_idx), device=self.device)
             f.w8_desc = torch.tensor([[f.slots[n][0], f.slots[n][2][0], f.slots[n][2][1]] for n in f.w8_idx], dtype=torch.long, device=self.device)
-        f.w8_amax.zero_()
-        ops.fp8_weights(f.w8_desc, f.p, f.w8, f.w8t, f.w8_amax, f.w8_dq)   # (one batched amax + two batched quantise launches instead of four per weight)
+            f.w8_stamp = None
+        f.fp8_active = True    # (FusedAdamW: step the block weights through csmae_adamw_fp8, which re-writes both mirrors with delayed scaling)
+        stamp = (f.version_stamp(), f.raw_writes)
+        if f.w8_stamp == stamp and not debug_opt("fp8_requant"):
+            return             # the mirrors were written by the optimizer step itself: nothing has touched the masters since
+        f.w8_amax[0].zero_()
+        ops.fp8_weights(f.w8_desc, f.p, f.w8, f.w8t, f.w8_amax[0], f.w8_dq)   # (one batched amax + two batched quantise launches instead of four per weight)
+        f.w8_stamp = stamp
 
     def _fp8_begin(self):
         """Start of a step in fp8 mode: weight mirrors, site counter, amax pools.  Activations / gradients are scaled with the amax the

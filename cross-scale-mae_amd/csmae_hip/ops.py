@@ -539,6 +539,13 @@ def adamw(tile_off, tile_cnt, tile_wd, p, g, m, v, lr, beta1, beta2, eps, step, 
                              st if st is not None else stream()), "csmae_adamw")
 
 
+def adamw_fp8(tile8, wd, p, g, m, v, lr, beta1, beta2, eps, step, p_lp, gate, w8, w8t, amax_prev, amax_next, dq, st=None):
+    """The fused AdamW step over 64 x 64 sub-blocks of fp8-mirrored weights (tile8 int64 [ntiles, 6]), writing W8 / W8^T with delayed scaling (csmae_adamw_fp8)."""
+    check(load().csmae_adamw_fp8(tile8.shape[0], _p(tile8), float(wd), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1), float(beta2), float(eps),
+                                 1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(p_lp), _p(gate), _p(w8), _p(w8t), _p(amax_prev), _p(amax_next), _p(dq),
+                                 st if st is not None else stream()), "csmae_adamw_fp8")
+
+
 def gate_accumulate(loss, slot, accumulate, st=None):
     check(load().csmae_gate_accumulate(_p(loss), _p(slot), int(accumulate), st if st is not None else stream()), "csmae_gate_accumulate")
 

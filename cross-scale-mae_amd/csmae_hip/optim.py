@@ -57,18 +57,27 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _plan(self, gi, group, flat):
         active = tuple(id(p) for p in group["params"] if p.grad is not None)
-        key = (gi, active)
+        # fp8 mode (the last forward ran an fp8 engine): the block Linear weights are stepped through csmae_adamw_fp8 in 64 x 64 sub-blocks, which writes
+        # their fp8 mirrors (W8 / W8^T) in the same pass — no re-quantisation launches at the start of the next forward
+        f8 = bool(getattr(flat, "fp8_active", False)) and getattr(flat, "w8", None) is not None
+        key = (gi, active, f8)
         if key not in self._plans:
             self._sync_steps()
             for old in [k for k in self._plans if k[0] == gi]:  # the group's active set changed: its old plan (and counter) is superseded
                 del self._plans[old]
-            offs, cnts, params, ks = [], [], [], []
+            offs, cnts, params, ks, t8, f8_names = [], [], [], [], [], set()
             ks_names = getattr(flat, "ks_names", None) if getattr(flat, "w_ks", None) is not None else None
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 params.append(p)
                 off, n, shape = flat.slot_of(p)
+                name = flat._by_id[id(p)]
+                if f8 and name in flat.w8_idx and len(shape) == 2 and shape[0] % 64 == 0 and shape[1] % 64 == 0:
+                    wi = flat.w8_idx[name]
+                    t8.extend((off, shape[0], shape[1], n0, k0, wi) for n0 in range(0, shape[0], 64) for k0 in range(0, shape[1], 64))
+                    f8_names.add(name)
+                    continue
                 # the K-slab mirror of a block Linear weight (Engine._refresh_ks) is written by the same launch: (weight offset, N, K) per tile
                 row = (off, shape[0], shape[1]) if (ks_names is not None and flat._by_id[id(p)] in ks_names) else (0, 0, 0)
                 for o in range(0, n, self.TILE):
@@ -80,6 +89,7 @@ class FusedAdamW(torch.optim.Optimizer):
             has_ks = any(r[2] for r in ks)
             self._plans[key] = dict(off=torch.tensor(offs, dtype=torch.long, device=dev), cnt=torch.tensor(cnts, dtype=torch.int32, device=dev),
                                     wd=torch.full((len(offs),), wd, device=dev), wd_host=wd, params=params,
+                                    t8=torch.tensor(t8, dtype=torch.long, device=dev).reshape(-1, 6) if t8 else None, f8_names=f8_names,
                                     ks=torch.tensor(ks, dtype=torch.long, device=dev).reshape(-1, 3) if has_ks else None,
                                     ks_names={flat._by_id[id(q)] for q in params} & set(ks_names) if has_ks else set(),
                                     step=self._common_step(params))
@@ -114,7 +124,8 @@ class FusedAdamW(torch.optim.Optimizer):
         flat = self._bind()
         g0 = flat.g.data_ptr()
         ks_before = getattr(flat, "ks_stamp", None) is not None and flat.ks_stamp == (flat.lp_stamp, flat.raw_writes)   # K-slab mirror consistent on entry
-        ks_written = set()
+        ks_written, f8_written = set(), set()
+        f8_before = getattr(flat, "w8_stamp", None) is not None and flat.w8_stamp == (flat.version_stamp(), flat.raw_writes)   # fp8 mirrors consistent on entry
         for gi, group in enumerate(self.param_groups):
             plan = self._plan(gi, group, flat)
             params = plan["params"]
@@ -132,8 +143,14 @@ class FusedAdamW(torch.optim.Optimizer):
                 plan["wd_host"] = wd
             b1, b2 = group["betas"]
             ks_ok = plan["ks"] is not None and flat.w_lp is not None and getattr(flat, "w_ks", None) is not None
-            ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp,
-                      gate=flat.gate, tile_ks=plan["ks"] if ks_ok else None, p_ks=flat.w_ks if ks_ok else None)
+            if plan["off"].numel():
+                ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp,
+                          gate=flat.gate, tile_ks=plan["ks"] if ks_ok else None, p_ks=flat.w_ks if ks_ok else None)
+            if plan["t8"] is not None:
+                flat.w8_amax[1].zero_()
+                ops.adamw_fp8(plan["t8"], wd, flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, flat.w_lp, flat.gate, flat.w8, flat.w8t,
+                              flat.w8_amax[0], flat.w8_amax[1], flat.w8_dq)
+                f8_written |= plan["f8_names"]
             # the kernel wrote the masters (and the bf16 mirror) behind torch's version counters: mirrors derived from it (fp8) are stale.  The K-slab
             # mirror is not, when this launch wrote it for every weight that has one and it was consistent before (Engine._refresh_ks's stamp)
             flat.raw_writes += 1
@@ -142,6 +159,12 @@ class FusedAdamW(torch.optim.Optimizer):
             self._dirty_steps = True
         if ks_before and ks_written and ks_written == set(flat.ks_names):   # every K-slab mirror was re-written by the launches above: still consistent
             flat.ks_stamp = (flat.lp_stamp, flat.raw_writes)
+        if f8_written:
+            flat.w8_amax.reverse()   # what this step measured is what the next rewrite scales with
+            if f8_before and f8_written == set(flat.w8_idx):   # every fp8 mirror was re-written from the stepped masters: consistent, Engine._refresh_fp8 has nothing to do
+                flat.w8_stamp = (flat.version_stamp(), flat.raw_writes)
+            else:
+                flat.w8_stamp = None
 
     def _sync_steps(self):
         """torch's per-parameter `step` entries are refreshed lazily (state_dict / checkpointing), not 250 tensors per step."""

@@ -202,15 +202,21 @@ __global__ __launch_bounds__(256) void fp8_colsum_partial_kernel(Dw8GroupArgs ga
   for (int e = 0; e < 16; ++e) s[e] = 0.f;
   if (col < d.ldy) {   // (rows are 16-byte multiples: a group is inside the row or beyond it; columns >= M inside the row hold padding and are dropped by the fold)
     const unsigned char* src = reinterpret_cast<const unsigned char*>(d.dY) + col;
-    for (long long r = r0 + rl; r < r1; r += 16) {
-      const uint4 v = *reinterpret_cast<const uint4*>(src + r * d.ldy);
+    auto add16 = [&](const uint4& v) {
       const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const auto lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)wv[q], false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)wv[q], true);
         s[4 * q] += lo[0]; s[4 * q + 1] += lo[1]; s[4 * q + 2] += hi[0]; s[4 * q + 3] += hi[1];
       }
+    };
+    long long r = r0 + rl;
+    for (; r + 48 < r1; r += 64) {   // four independent 16-byte loads in flight per thread (one per iteration left the kernel at a third of the HBM rate)
+      const uint4 v0 = *reinterpret_cast<const uint4*>(src + r * d.ldy), v1 = *reinterpret_cast<const uint4*>(src + (r + 16) * d.ldy);
+      const uint4 v2 = *reinterpret_cast<const uint4*>(src + (r + 32) * d.ldy), v3 = *reinterpret_cast<const uint4*>(src + (r + 48) * d.ldy);
+      add16(v0); add16(v1); add16(v2); add16(v3);
     }
+    for (; r < r1; r += 16) add16(*reinterpret_cast<const uint4*>(src + r * d.ldy));
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) red[rl][cg * 16 + e] = s[e];

@@ -79,6 +79,85 @@ extern "C" int csmae_adamw(long long ntiles, const long long* tile_off, const in
   return csmae_check_launch("csmae_adamw");
 }
 
+// ---- the same step for the block Linear weights of an fp8-mode model, writing their fp8 mirrors on the way (BASELINE.json configs[4]): W8 [out][in] for the
+// forward products and W8^T [in][out] for dX (csmae_gemm_fp8 reads two K-contiguous operands).  A workgroup owns a 64 x 64 sub-block of one weight
+// (tile8[tile] = {flat offset of the weight, N = out, K = in, n0, k0, weight index}; N, K multiples of 64): its rows are 256-B segments of the fp32
+// buffers, the quantised block crosses LDS once so that both mirrors leave in 64-byte row segments.  DELAYED scaling, as for the activations: the scale
+// is 448 / amax of the weight ONE STEP EARLIER (amax_prev [nw][64] partial maxima; a weight moves by ~lr per step, far below an e4m3 step), the new
+// maximum is folded into amax_next (zeroed by the caller), dq[w] = amax_prev / 448.  Replaces csmae_fp8_weights' three launches per step
+// (a second read of the 2.5 GB of masters).  A tripped gate leaves weights and mirrors alone and carries the old maxima over.
+__global__ __launch_bounds__(256) void adamw_f8_kernel(const long long* __restrict__ tile8, float wd, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2, bf16_t* __restrict__ p_lp,
+                                                       const float* __restrict__ gate, unsigned char* __restrict__ w8, unsigned char* __restrict__ w8t,
+                                                       const float* __restrict__ amax_prev, float* __restrict__ amax_next, float* __restrict__ dq) {
+  const long long* t = tile8 + (long long)blockIdx.x * 6;
+  const long long wbase = t[0];
+  const int N = (int)t[1], K = (int)t[2], n0 = (int)t[3], k0 = (int)t[4], wi = (int)t[5];
+  const int lane = threadIdx.x & 63;
+  const float am = wave_max(amax_prev[(long long)wi * 64 + lane]);
+  if (gate != nullptr && !isfinite(gate[0])) {
+    if (n0 == 0 && k0 == 0 && threadIdx.x == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_next) + (long long)wi * 64, __float_as_uint(am));
+    return;
+  }
+  __shared__ unsigned q8[64][17];   // the block's fp8 bytes: row r = 64 bytes (+ pad)
+  __shared__ float red[4];
+  const float scale = am > 0.f ? 448.0f / am : 1.f;
+  if (n0 == 0 && k0 == 0 && threadIdx.x == 0) dq[wi] = am > 0.f ? am / 448.0f : 1.f;
+  const float step_size = lr / bc1, rbc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+  const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;   // 16 threads x 4 columns per row, 16 rows per pass
+  float seen = 0.f;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = pass * 16 + r0;
+    const long long e = wbase + (long long)(n0 + r) * K + k0 + c4;
+    f4_t pp = *reinterpret_cast<f4_t*>(p + e), gg = *reinterpret_cast<const f4_t*>(g + e);
+    f4_t mm = *reinterpret_cast<f4_t*>(m + e), vv = *reinterpret_cast<f4_t*>(v + e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pp[k] *= decay;
+      mm[k] = mm[k] + (1.f - b1) * (gg[k] - mm[k]);
+      vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+      pp[k] -= step_size * (mm[k] / (sqrtf(vv[k]) * rbc2 + eps));
+      const float a = fabsf(pp[k]);
+      seen = fmaxf(seen, a == a ? a : INFINITY);
+    }
+    *reinterpret_cast<f4_t*>(p + e) = pp; *reinterpret_cast<f4_t*>(m + e) = mm; *reinterpret_cast<f4_t*>(v + e) = vv;
+    if (p_lp) st4<bf16_t>(p_lp + e, pp);
+    f4_t q = pp * scale;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = q[k] != q[k] ? q[k] : fminf(fmaxf(q[k], -448.0f), 448.0f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
+    *reinterpret_cast<unsigned*>(w8 + e) = (unsigned)w;
+    q8[r][c4 >> 2] = (unsigned)w;
+  }
+  __syncthreads();
+  // transposed mirror: thread -> column c of the block (a row of W8^T), 4 consecutive block rows r4 .. r4 + 3 (bytes along n)
+  const unsigned char* qb = reinterpret_cast<const unsigned char*>(&q8[0][0]);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int c = pass * 16 + r0, r4 = (threadIdx.x & 15) * 4;
+    const unsigned b0 = qb[(r4 + 0) * 68 + c], b1_ = qb[(r4 + 1) * 68 + c], b2_ = qb[(r4 + 2) * 68 + c], b3 = qb[(r4 + 3) * 68 + c];
+    *reinterpret_cast<unsigned*>(w8t + wbase + (long long)(k0 + c) * N + n0 + r4) = b0 | (b1_ << 8) | (b2_ << 16) | (b3 << 24);
+  }
+  seen = wave_max(seen);
+  if (lane == 0) red[threadIdx.x >> 6] = seen;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    seen = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (seen > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_next) + (long long)wi * 64 + (blockIdx.x & 63), __float_as_uint(seen));
+  }
+}
+extern "C" int csmae_adamw_fp8(long long ntiles, const long long* tile8, float weight_decay, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                               float beta2, float eps, float bias_correction1, float bias_correction2, void* p_lp, const float* gate, void* w8, void* w8t,
+                               const float* amax_prev, float* amax_next, float* dq, void* stream) {
+  CSMAE_REQUIRE(ntiles > 0 && tile8 && p && g && m && v && w8 && w8t && amax_prev && amax_next && dq, "csmae_adamw_fp8: null argument");
+  CSMAE_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, "csmae_adamw_fp8: bias corrections must be positive (step >= 1)");
+  hipLaunchKernelGGL(adamw_f8_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, tile8, weight_decay, p, g, m, v, lr, beta1, beta2, eps, bias_correction1,
+                     bias_correction2, (bf16_t*)p_lp, gate, (unsigned char*)w8, (unsigned char*)w8t, amax_prev, amax_next, dq);
+  return csmae_check_launch("csmae_adamw_fp8");
+}
+
 // ---- global gradient norm + clip over the flat gradient buffer (util/misc.py:299-335: `torch.nn.utils.clip_grad_norm_(parameters, clip_grad)`
 // or `get_grad_norm_`).  All gradients are one contiguous fp32 buffer (slots of frozen / unused parameters hold zeros), so the
 // 2-norm is one streaming pass in a fixed order (deterministic two-stage sum, fp32 like torch's foreach norm) and the clip is one

@@ -273,6 +273,13 @@ int csmae_augment_u8(long long N, int C, int Hmax, int Wmax, int S, const unsign
 int csmae_adamw(long long ntiles, const long long* tile_off, const int* tile_cnt, const float* tile_wd, float* p, const float* g,
                 float* m, float* v, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
                 void* p_lp, const float* gate, const long long* tile_ks, void* p_ks, void* stream);
+/* The same step for the block Linear weights of an fp8-mode model (ABI version 7), writing their fp8 mirrors on the way: W8 [out][in] (e4m3) for the forward
+ * products, W8^T [in][out] for dX — instead of csmae_fp8_weights' three launches per step.  tile8: device int64 [ntiles][6] = {flat offset of the weight,
+ * N = out, K = in (multiples of 64), n0, k0 (the workgroup's 64 x 64 sub-block), weight index}.  Delayed scaling: scale 448 / amax_prev[w] (64 partial
+ * maxima per weight, one step old), the new maximum into amax_next[w] (zeroed by the caller), dq[w] = amax_prev[w] / 448.  One weight-decay value per launch. */
+int csmae_adamw_fp8(long long ntiles, const long long* tile8, float weight_decay, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                    float beta2, float eps, float bias_correction1, float bias_correction2, void* p_lp, const float* gate, void* w8, void* w8t,
+                    const float* amax_prev, float* amax_next, float* dq, void* stream);
 int csmae_gate_accumulate(const float* loss, float* slot, int accumulate, void* stream);
 /* util/misc.py:310-318 (`torch.nn.utils.clip_grad_norm_(parameters, clip_grad)`) / :338-355 (`get_grad_norm_`) on the flat gradient
  * buffer: out[0] = total 2-norm, out[1] = min(1, max_norm / (norm + 1e-6)); g *= out[1] in place when max_norm > 0 (<= 0: norm only).

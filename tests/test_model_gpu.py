@@ -582,6 +582,27 @@ def test_fp8_step_vs_reference_and_oracle(tag):
     FusedAdamW(add_weight_decay(m, 0.05), lr=1e-4, betas=(0.9, 0.95)).step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in m.parameters())
+    # the optimizer step wrote the fp8 weight mirrors itself (csmae_adamw_fp8: W8 and W8^T of every block Linear, delayed scaling): the next forward has
+    # nothing to re-quantise, the transposed mirror is the transpose byte for byte, and the values agree with a fresh quantisation of the stepped masters
+    f = m._flat
+    assert f.w8_stamp == (f.version_stamp(), f.raw_writes), "FusedAdamW did not leave the fp8 weight mirrors consistent"
+    w8a, w8ta, dqa = f.w8.clone(), f.w8t.clone(), f.w8_dq.clone()
+    f.w8_stamp = None
+    eng._refresh_fp8()          # current scaling from the masters
+    for name in (f"encoder.{cfg['Ne'] - 1}.mlp.fc1.weight", "decoder.0.attn.qkv.weight", "encoder.0.attn.proj.weight"):
+        o, n, shape = f.slots[name]
+        wi = f.w8_idx[name]
+        a = w8a[o:o + n].view(torch.float8_e4m3fn).float() * dqa[wi]
+        b = f.w8[o:o + n].view(torch.float8_e4m3fn).float() * f.w8_dq[wi]
+        w = f.p[o:o + n]
+        # (an e4m3 step in the top binade is 32 / 448 = 7.1 % of the tensor's maximum: each mirror within half a step of the master, the two within one step of each other)
+        assert float((a - w).abs().max()) <= 0.0375 * float(w.abs().max()) and float((a - b).abs().max()) <= 0.075 * float(w.abs().max()), name
+        assert float((a - w).norm() / w.norm()) < 0.04, (name, float((a - w).norm() / w.norm()))
+        assert torch.equal(w8ta[o:o + n].view(shape[1], shape[0]), w8a[o:o + n].view(shape[0], shape[1]).t()), f"{name}: W8^T is not the transpose of W8"
+    m.zero_grad(set_to_none=True)
+    m._test_draws = dict(noise=noise, box=box)
+    loss2, _, _ = m(imgs.cuda(), mask_ratio=0.75)
+    assert torch.isfinite(loss2) and 0.5 * first < float(loss2) < first   # (one AdamW step at lr 1e-4 later: the loss went down, on the mirrors the step wrote)
 
 
 def test_full_size_vitb_224_n128_vs_reference():
