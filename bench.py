@@ -345,7 +345,8 @@ def main():
         log("kernel timing pass done")
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["work"] for v in summ.values())
-        kernel = dict(name="GEMM family: gemm_bf16_k2_kernel (128x256 tiles, two workgroups per CU) + gemm_bf16_k64_kernel + gemm_dw_group_kernel (256x256 tiles) (MFMA 16x16x32 bf16)" + (" + gemm_fp8_kernel (MFMA 16x16x128 f8f6f4)" if a.dtype == "fp8" else "") +
+        kernel = dict(name="GEMM family: gemm_bf16_k2_kernel (128x256 tiles, two workgroups per CU) + gemm_bf16_k8_kernel (128x512 full-row tiles, LayerNorm in the epilogue) + gemm_bf16_k64_kernel + gemm_dw_group_kernel (256x256 tiles) (MFMA 16x16x32 bf16)" +
+                      (" + gemm_fp8_pipe_kernel / gemm_fp8_dw_group_kernel (MFMA 16x16x128 f8f6f4)" if a.dtype == "fp8" else "") +
                       "; serialised on one stream for the HIP-event timing (every launch alone on the chip; in the overlapped step the weight-gradient launches are held to 160 workgroups)", launches_per_step=sum(v["launches"] for v in summ.values()),
                       ms_per_step=round(tot_ms, 3), tflops=round(tot_fl / tot_ms / 1e9, 1),
                       by_layout={k: dict(ms=round(v["ms"], 3), launches=v["launches"], tflops=round(v["work"] / v["ms"] / 1e9, 1)) for k, v in summ.items()})

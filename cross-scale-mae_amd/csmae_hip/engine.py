@@ -292,6 +292,7 @@ class Engine:
         self.ln_fuse = self.T == BF16 and not self.fp8 and self.res_dtype == torch.bfloat16 and not debug_opt("no_lnfuse")
         self.ln_fuse_fwd = self.ln_fuse and not debug_opt("no_lnfuse_fwd")   # (A/B aids: one direction only)
         self.ln_fuse_bwd = self.ln_fuse and not debug_opt("no_lnfuse_bwd")
+        self._ln_fuse_mask = int(debug_opt("lnfuse_mask", "15"))   # A/B aid: bit 0 proj + norm2, 1 fc2 + next norm1, 2 fc1-dX + norm2', 3 qkv-dX + norm1'
         self.use_ks = not debug_opt("no_kslab")   # (CSMAE_DEBUG=no_kslab: forward products through csmae_gemm with the plain weight mirror; no K-slab mirror is kept)
         self._dw_slots = int(debug_opt("dw_slots", "160"))   # workgroups of a weight-gradient launch: ~5/8 of the CUs, the rest runs the main stream
         # ... per stack ("enc,dec") for the blocks' own launches: the decoder's long products (50 k tokens) run best on half the chip —
@@ -608,13 +609,13 @@ class Engine:
         d8 = (lambda name, stage, n: S[name][i][r] if keep8 else stage[: Mr * n].view(Mr, n))
         e1 = self._emit_to(k1, d8("y1_8", ws_q_a[ln], Dm), 0) if self.fp8 else None
         fuse = self._ln_fused_fwd(Mr, Dm)
-        if not (fuse and i > 0):   # (fused: the previous block's fc2 epilogue has already left norm1(x_in) in y1 and its statistics)
+        if not (fuse and (self._ln_fuse_mask & 2) and i > 0):   # (fused: the previous block's fc2 epilogue has already left norm1(x_in) in y1 and its statistics)
             ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, st=st)
         self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=ln, site=k1, a8=e1[0] if e1 else None)
         # (fp8 mode) attention leaves its output as fp8 bytes for attn.proj (q_a: y1 has been consumed by the qkv GEMM, y2 comes after proj)
         eo = self._emit_to(ko, d8("o_8", ws_q_a[ln], Dm), 0) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
         ops.attn_fwd(qkv, o, lse, nb, T, H, Dm // H, emit=eo, st=st)
-        if fuse:   # x_mid = x_in + proj(o) and y2 = norm2(x_mid) in one kernel
+        if fuse and (self._ln_fuse_mask & 1):   # x_mid = x_in + proj(o) and y2 = norm2(x_mid) in one kernel
             ops.gemm_ln_fwd(o, self._ks(pre + "attn.proj.weight"), P(pre + "attn.proj.bias"), x_in, x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"),
                             y2, stt[2], stt[3], st=st)
             e2 = None
@@ -630,7 +631,7 @@ class Engine:
                  emit_dst=h8)
         if keep8:   # which of the block's kept copies this pass really wrote (none without amax history; o only from the LDS-resident attention kernels)
             self._fp8_kept[(id(S), i)] = dict(y1=e1 is not None, o=eo is not None, y2=e2 is not None, h=eh is not None)
-        if fuse and i + 1 < S["xm"].shape[0]:   # x_out = x_mid + fc2(h) and the NEXT block's y1 = norm1(x_out) in one kernel
+        if fuse and (self._ln_fuse_mask & 2) and i + 1 < S["xm"].shape[0]:   # x_out = x_mid + fc2(h) and the NEXT block's y1 = norm1(x_out) in one kernel
             nxt = pre[: pre.rstrip(".").rfind(".") + 1] + f"{i + 1}."
             sn = [a[r] for a in S["st"][i + 1][:2]]
             ops.gemm_ln_fwd(h, self._ks(pre + "mlp.fc2.weight"), P(pre + "mlp.fc2.bias"), x_mid, x_out, P(nxt + "norm1.weight"), P(nxt + "norm1.bias"),
