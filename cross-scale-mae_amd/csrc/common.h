@@ -96,6 +96,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// The same sum for a FULL wave (all 64 lanes active — the result is read from lane 63) on DPP moves only: quad swaps, half-row and row mirrors leave the row's
+// sum in each of its 16 lanes, row_bcast:15 / :31 carry it across the four rows.  `wave_sum` above goes through ds_bpermute_b32 (the LDS crossbar): six
+// dependent round trips of ~100 clocks per sum — more than a LayerNorm row's arithmetic.  Different summation tree: last-bit differences against wave_sum.
+__device__ __forceinline__ float wave_sum64(float v) {
+#define CSMAE_DPP_ADD(ctrl, rmask, bctl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, bctl))
+  CSMAE_DPP_ADD(0xB1, 0xF, true);    // quad_perm [1,0,3,2]
+  CSMAE_DPP_ADD(0x4E, 0xF, true);    // quad_perm [2,3,0,1]
+  CSMAE_DPP_ADD(0x141, 0xF, true);   // row_half_mirror
+  CSMAE_DPP_ADD(0x140, 0xF, true);   // row_mirror
+  CSMAE_DPP_ADD(0x142, 0xA, false);  // row_bcast:15 into rows 1 and 3
+  CSMAE_DPP_ADD(0x143, 0xC, false);  // row_bcast:31 into rows 2 and 3
+#undef CSMAE_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

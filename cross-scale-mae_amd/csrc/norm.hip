@@ -2,6 +2,9 @@
 // BatchNorm1d-over-token-positions + ReLU (models_mae/MLP.py:4-10).  All HBM-bound: one wave per LayerNorm row
 // (wave-shuffle reductions, 16-B accesses), one workgroup per BatchNorm channel.
 #include "common.h"
+#include <type_traits>
+typedef __amdgpu_buffer_rsrc_t brsrc_t;
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------ LayerNorm forward
 template <typename TX, typename TO, int NV>
@@ -23,14 +26,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const T
       v[i] = c < nv ? ld4<TX>(x + row * D + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
       s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
-    const float mu = wave_sum(s) / D;
+    const float mu = wave_sum64(s) / D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = lane + i * 64;
       if (c < nv) { f4_t d = v[i] - mu; q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]; }
     }
-    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    const float rs = rsqrtf(wave_sum64(q) / D + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = lane + i * 64;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, NV == 3 ? 4 : (NV == 2 ? 5 : 1)) void ln_bwd_k
         s2 += t[0] + t[1] + t[2] + t[3];
       }
     }
-    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+    s1 = wave_sum64(s1) / D; s2 = wave_sum64(s2) / D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = lane + i * 64;
@@ -129,6 +132,84 @@ __global__ __launch_bounds__(256, NV == 3 ? 4 : (NV == 2 ? 5 : 1)) void ln_bwd_k
       if (part) *reinterpret_cast<f4_t*>(part + (long long)blockIdx.x * 2 * D + D + c * 4) = s;
       else for (int k = 0; k < 4; ++k) unsafeAtomicAdd(dbeta + c * 4 + k, s[k]);
     }
+  }
+}
+
+// The throughput mode's instance (dy, x, dres_in, dx_out all bf16, no second copy) holding a row's three inputs PACKED (8 bytes per lane and load) through
+// the two reductions and unpacking them at each use: 54 instead of 90 live registers at D = 768, i.e. six instead of four waves per SIMD — a wave handles one
+// row at a time and is bound by its row's HBM round trip, so rows in flight per CU are what the kernel's bandwidth consists of (3.7 TB/s alone at four waves).
+template <int NV, int MINW>
+__global__ __launch_bounds__(256, MINW) void ln_bwd_bf16_kernel(long long M, int D, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma, const bf16_t* __restrict__ dres_in,
+                                                                bf16_t* __restrict__ dx_out, float* __restrict__ part) {
+  __shared__ float red[4 * 64 * 4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  f4_t gm[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    gm[i] = c < nv ? *reinterpret_cast<const f4_t*>(gamma + c * 4) : f4_t{0.f, 0.f, 0.f, 0.f};
+    ag[i] = f4_t{0.f, 0.f, 0.f, 0.f}; ab[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  auto up = [](u2_t u) { return f4_t{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)}; };
+  // the four [M][D] bf16 tensors share one element offset: buffer resources + ONE 32-bit byte offset per row (lane's first column group; group i is 512 B further)
+  // instead of a 64-bit address per load (18 of the first version's registers); columns beyond D are masked to an out-of-range offset (zeros in, nothing out)
+  const long long bytes = M * (long long)D * 2;
+  const brsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, (int)(unsigned)bytes, 0x00020000);
+  const brsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, (int)(unsigned)bytes, 0x00020000);
+  const brsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dres_in ? dres_in : dy), 0, dres_in ? (int)(unsigned)bytes : 0, 0x00020000);
+  const brsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(dx_out, 0, (int)(unsigned)bytes, 0x00020000);
+  for (long long row = (long long)blockIdx.x * 4 + w; row < M; row += (long long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const unsigned voff = (unsigned)((row * D + lane * 4) * 2);
+    u2_t rd[NV], rx[NV], rr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const unsigned o = (lane + i * 64 < nv) ? voff + (unsigned)(i * 512) : 0xFFFFFFF0u;
+      rr[i] = __builtin_bit_cast(u2_t, __builtin_amdgcn_raw_buffer_load_b64(rR, o, 0, 0));
+      rd[i] = __builtin_bit_cast(u2_t, __builtin_amdgcn_raw_buffer_load_b64(rD, o, 0, 0));
+      rx[i] = __builtin_bit_cast(u2_t, __builtin_amdgcn_raw_buffer_load_b64(rX, o, 0, 0));
+    }
+    float s1 = 0.f, s2 = 0.f;
+    const float c0 = -mu * rs;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + i * 64 < nv) {
+        const f4_t d = up(rd[i]), xh = up(rx[i]) * rs + c0, g = d * gm[i];
+        ag[i] += d * xh; ab[i] += d;
+        s1 += (g[0] + g[1]) + (g[2] + g[3]);
+        const f4_t t = g * xh;
+        s2 += (t[0] + t[1]) + (t[2] + t[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (one column group at a time: unpacked, all groups at once are the 36 registers this instance exists to save)
+    }
+    s1 = wave_sum64(s1) / D; s2 = wave_sum64(s2) / D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const unsigned o = (lane + i * 64 < nv) ? voff + (unsigned)(i * 512) : 0xFFFFFFF0u;
+      const f4_t xh = up(rx[i]) * rs + c0, g = up(rd[i]) * gm[i];
+      const f4_t o4 = (g - s1 - xh * s2) * rs + up(rr[i]);
+      __builtin_amdgcn_raw_buffer_store_b64(u2_t{pack2bf(o4[0], o4[1]), pack2bf(o4[2], o4[3])}, rO, o, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    __syncthreads();
+    *reinterpret_cast<f4_t*>(red + (w * 64 + lane) * 4) = ag[i];
+    __syncthreads();
+    if (w == 0 && c < nv)
+      *reinterpret_cast<f4_t*>(part + (long long)blockIdx.x * 2 * D + c * 4) = *reinterpret_cast<f4_t*>(red + lane * 4) + *reinterpret_cast<f4_t*>(red + (64 + lane) * 4) +
+                                                                             *reinterpret_cast<f4_t*>(red + (128 + lane) * 4) + *reinterpret_cast<f4_t*>(red + (192 + lane) * 4);
+    __syncthreads();
+    *reinterpret_cast<f4_t*>(red + (w * 64 + lane) * 4) = ab[i];
+    __syncthreads();
+    if (w == 0 && c < nv)
+      *reinterpret_cast<f4_t*>(part + (long long)blockIdx.x * 2 * D + D + c * 4) = *reinterpret_cast<f4_t*>(red + lane * 4) + *reinterpret_cast<f4_t*>(red + (64 + lane) * 4) +
+                                                                                 *reinterpret_cast<f4_t*>(red + (128 + lane) * 4) + *reinterpret_cast<f4_t*>(red + (192 + lane) * 4);
   }
 }
 
@@ -214,6 +295,15 @@ static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, con
   dim3 grid(blocks), block(256);
   int nv = cdiv(D, 256);
 #define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, (const TX*)dres_in, (TX*)dx_out, (TLP*)dx_lp, dgamma, dbeta, part, em)
+  // the all-bf16 stream with deferred parameter gradients and no fp8 copy (every block LayerNorm of the bf16 step): the packed-register instance
+  static const bool no_packed = csmae_debug_opt("ln_bwd_unpacked") != nullptr;   // A/B aid
+  if (std::is_same<TDY, bf16_t>::value && std::is_same<TX, bf16_t>::value && !dx_lp && !dgamma && part && !em.q && !no_packed && D % 4 == 0 && nv >= 2 && nv <= 4 &&
+      (M + 4) * (long long)D * 2 < 0xFFFFFFF0ll) {
+#define LNBP(NVV, MW) hipLaunchKernelGGL((ln_bwd_bf16_kernel<NVV, MW>), grid, block, 0, st, M, D, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres_in, (bf16_t*)dx_out, part)
+    if (nv == 2) LNBP(2, 8); else if (nv == 3) LNBP(3, 5); else LNBP(4, 4);
+#undef LNBP
+    return;
+  }
   switch (nv) { case 1: LNB(1); break; case 2: LNB(2); break; case 3: LNB(3); break; case 4: LNB(4); break; case 5: LNB(5); break; default: LNB(8); }
 #undef LNB
   if (part && dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64), 1), dim3(1024), 0, st, blocks, D, part, 0ll, (float*)nullptr, (const long long*)nullptr, dgamma, dbeta);
