@@ -148,16 +148,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
       m = fmaxf(fmaxf(m, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
       s[f] = a;
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = xrow_max(m);
     m *= c2;      // the scale (positive) is applied inside the exponent's fma: p = 2^(s c2 - max(s) c2), one multiply per row instead of one per score
     float l = 0.f;
 #pragma unroll
     for (int f = 0; f < NKF; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { float p = __builtin_amdgcn_exp2f(fmaf(s[f][r], c2, -m)); s[f][r] = p; l += p; }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xrow_sum(l);
     const float inv = 1.0f / l;
     s8_t fp[NKF / 2];
 #pragma unroll

@@ -110,6 +110,21 @@ __device__ __forceinline__ float wave_sum64(float v) {
 #undef CSMAE_DPP_ADD
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// max / sum over the four 16-lane rows of a wave, lane by lane (lanes t, t + 16, t + 32, t + 48: what `x = op(x, __shfl_xor(x, 16)); x = op(x, __shfl_xor(x, 32))`
+// computes, bit for bit — the same pairs are combined) on gfx950's v_permlane16_swap / v_permlane32_swap instead of two dependent ds_bpermute round trips
+// through the LDS crossbar: swapping a register with a copy of itself leaves every lane's partner value in one of the two.
+__device__ __forceinline__ float xrow_max(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xrow_sum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

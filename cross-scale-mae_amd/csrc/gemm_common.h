@@ -73,6 +73,9 @@ __device__ __forceinline__ f4_t gp_q8_unpack4(unsigned p) {
   return (q - GP_Q8_OFF) * (1.0f / GP_Q8_SCALE);
 }
 
+// the neighbouring lane's value (lane ^ 1) as ONE DPP move (quad_perm [1,0,3,2]); `__shfl_xor(x, 1)` is a ds_bpermute_b32 round trip through the LDS crossbar
+__device__ __forceinline__ unsigned lane_xor1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true); }
+
 // ------------------------------------------------------------------------------------ epilogue
 template <typename TC>
 __device__ __forceinline__ void epi_store4(const GemmArgs& p, int m, int n, f4_t v) {
@@ -334,7 +337,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
           const bool odd = lane & 1;
           const uint2 send = odd ? gp_prev : mine;
           uint2 recv;
-          recv.x = (unsigned)__shfl_xor((int)send.x, 1); recv.y = (unsigned)__shfl_xor((int)send.y, 1);
+          recv.x = lane_xor1(send.x); recv.y = lane_xor1(send.y);
           if (!pair_ok) { st8(gm - RPP, gp_prev); st8(gm, mine); }
           else {   // ONE store instruction for the lane pair's two rows (an even-lane store and an odd-lane store, each half empty, cost what two 8-byte stores cost)
             const int row = odd ? gm : gm - RPP;
@@ -436,7 +439,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8b(const GemmArgs& p, f4_t (&
           else {
             const uint2 send = odd ? gp_prev : mine;
             uint2 recv;
-            recv.x = (unsigned)__shfl_xor((int)send.x, 1); recv.y = (unsigned)__shfl_xor((int)send.y, 1);
+            recv.x = lane_xor1(send.x); recv.y = lane_xor1(send.y);
             if (!pair_ok) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, gp_prev), rsL, offL_prev, 0, 0); __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, mine), rsL, offL, 0, 0); }
             else {
               const uint4 val = odd ? make_uint4(recv.x, recv.y, mine.x, mine.y) : make_uint4(gp_prev.x, gp_prev.y, recv.x, recv.y);
