@@ -110,6 +110,18 @@ __device__ __forceinline__ float wave_sum64(float v) {
 #undef CSMAE_DPP_ADD
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// ... and the maximum of a FULL wave the same way (fp8 amax bookkeeping of the producing kernels' epilogues: every lane is active there)
+__device__ __forceinline__ float wave_max64(float v) {
+#define CSMAE_DPP_MAX(ctrl, rmask, bctl) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, rmask, 0xF, bctl)))
+  CSMAE_DPP_MAX(0xB1, 0xF, false);
+  CSMAE_DPP_MAX(0x4E, 0xF, false);
+  CSMAE_DPP_MAX(0x141, 0xF, false);
+  CSMAE_DPP_MAX(0x140, 0xF, false);
+  CSMAE_DPP_MAX(0x142, 0xA, false);   // (rows outside the mask keep their own value: old = v)
+  CSMAE_DPP_MAX(0x143, 0xC, false);
+#undef CSMAE_DPP_MAX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 // max / sum over the four 16-lane rows of a wave, lane by lane (lanes t, t + 16, t + 32, t + 48: what `x = op(x, __shfl_xor(x, 16)); x = op(x, __shfl_xor(x, 32))`
 // computes, bit for bit — the same pairs are combined) on gfx950's v_permlane16_swap / v_permlane32_swap instead of two dependent ds_bpermute round trips
 // through the LDS crossbar: swapping a register with a copy of itself leaves every lane's partner value in one of the two.
@@ -224,7 +236,7 @@ template <> __device__ __forceinline__ void gelu_both4<bf16_t>(f4_t x, f4_t& h, 
 struct Fp8Emit { unsigned char* q; const float* amax_prev; float* amax_next; float* dq; int fmt; };
 __device__ __forceinline__ float fp8_emit_scale(const Fp8Emit& e, int lane, float& qmax) {
   qmax = e.fmt == 0 ? 448.0f : 57344.0f;
-  const float am = wave_max(e.amax_prev[lane & 63]);
+  const float am = wave_max64(e.amax_prev[lane & 63]);
   if (blockIdx.x == 0 && threadIdx.x == 0) e.dq[0] = am > 0.f ? am / qmax : 1.f;
   return am > 0.f ? qmax / am : 1.f;
 }
@@ -242,7 +254,7 @@ __device__ __forceinline__ unsigned fp8_pack4(f4_t v, float scale, float qmax, i
   return (unsigned)p;
 }
 __device__ __forceinline__ void fp8_emit_amax(const Fp8Emit& e, float seen, int lane) {
-  seen = wave_max(seen);
+  seen = wave_max64(seen);
   if (lane == 0 && seen > 0.f) atomicMax(reinterpret_cast<unsigned*>(e.amax_next) + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(seen));
 }
 

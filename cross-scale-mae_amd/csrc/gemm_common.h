@@ -243,7 +243,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   const float qmax = p.q_fmt == 0 ? 448.0f : 57344.0f;
   float qscale = 1.f, qseen = 0.f;
   if (emit) {
-    const float am = wave_max(p.q_amax_prev[lane]);
+    const float am = wave_max64(p.q_amax_prev[lane]);
     qscale = am > 0.f ? qmax / am : 1.f;
     if (blockIdx.x == 0 && threadIdx.x == 0) p.q_dq[0] = am > 0.f ? am / qmax : 1.f;
   }
@@ -358,7 +358,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
     }
   }
   if (emit) {   // this wave's share of the new amax: one atomic per wave, spread over the 64 slots
-    qseen = wave_max(qseen);
+    qseen = wave_max64(qseen);
     if (lane == 0 && qseen > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q_amax_next) + ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 63), __float_as_uint(qseen));
   }
 }
