@@ -300,7 +300,7 @@ static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, con
   if (std::is_same<TDY, bf16_t>::value && std::is_same<TX, bf16_t>::value && !dx_lp && !dgamma && part && !em.q && !no_packed && D % 4 == 0 && nv >= 2 && nv <= 4 &&
       (M + 4) * (long long)D * 2 < 0xFFFFFFF0ll) {
 #define LNBP(NVV, MW) hipLaunchKernelGGL((ln_bwd_bf16_kernel<NVV, MW>), grid, block, 0, st, M, D, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres_in, (bf16_t*)dx_out, part)
-    if (nv == 2) LNBP(2, 8); else if (nv == 3) LNBP(3, 5); else LNBP(4, 4);
+    if (nv == 2) LNBP(2, 6); else if (nv == 3) LNBP(3, 5); else LNBP(4, 4);
 #undef LNBP
     return;
   }
