@@ -694,6 +694,13 @@ class Engine:
         tw = self.fp8 and self.fp8_dw and lps8 is not None
         dpre8 = ws.t4_8[self._tog][: M * 4 * Dm].view(M, 4 * Dm) if tw else None
         ed = (self._emit_to(kd, dpre8, 1) if tw else self._emit(kd, ws.q_b[0], M, 4 * Dm, 1)) if self.fp8 else None
+        if tw and kc is None and ws.fp8_hist and self._fp8_fuse:
+            # the stack's first block: its incoming residual gradient comes from a kernel that emits no fp8 copy (latent_grad_finish).  The fc2-dX product
+            # quantises it anyway (one pass, delayed scaling): into the buffer's fp8 twin instead of a staging buffer, so that the weight gradients of
+            # fc2 can read it too.  (Same position in the site order as the allocation inside _mm that it replaces.)
+            kc = self._fp8_alloc()
+            c8 = lps8[k]
+            ops.fp8_quantize(cur, c8, ws.fp8_amax[1][kc], ws.fp8_dq[kc:kc + 1], fmt=ops.FP8_E5M2, amax_next=ws.fp8_amax[0][kc], st=st)
         # the kernels whose outputs a weight-gradient launch waits for carry that launch's event themselves (an event recorded behind them
         # is a marker packet: ~5 us of idle main stream each, two per block)
         carried = ops._timer is None and not os.environ.get("CSMAE_DW_MAIN")
