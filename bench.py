@@ -50,7 +50,7 @@ def build(device, batch, world, loss="mse", preset="base"):
     model.to(device).train()
     model.compute_dtype = torch.bfloat16
     lr = 5e-5 * batch * world / 256  # main_pretrain.py:406-412 (blr 5e-5)
-    opt = FusedAdamW(add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95))
+    opt = FusedAdamW(add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95), overlap=True)   # (the step runs under the next forward pass's first layers, as main_pretrain.py runs it)
     wrapped = DataParallel(model) if world > 1 else model
     return model, wrapped, opt
 

@@ -278,6 +278,7 @@ class Engine:
         self._gen_done = -1
         self.side, self.main, self.aux = None, None, None
         self._fwd_streams = []
+        self._so = {}            # raw stream handle -> torch stream object of the forward pass in flight (_opt_gate)
         self._events, self._ev_i, self._side_reads, self._tog = [], 0, {}, 0
         self._side_seq, self._side_waited = 0, 0   # weight-gradient launches issued / the youngest one the main stream has waited for
         self._dw_cache = {}
@@ -334,10 +335,12 @@ class Engine:
             self.flat.fp8_active = False
         stamp = self.flat.version_stamp()
         if stamp != self.flat.lp_stamp:
+            self._opt_gate()
             ops.cast_bf16(self.flat.p, self.flat.w_lp)
             self.flat.lp_stamp = stamp
         if self.Pp != self.cfg["P"]:
             P = self.cfg["P"]
+            self._opt_gate()
             self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
             self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
         self._refresh_ks()
@@ -357,6 +360,7 @@ class Engine:
             f.ks_stamp = None
         stamp = (f.lp_stamp, f.raw_writes)
         if stamp != f.ks_stamp and f.ks_desc.shape[0]:
+            self._opt_gate()
             # on the auxiliary stream, under the stem (crop, masking, patch embedding: ~0.2 ms before the first block needs a weight): the
             # 90-us launch is off the main chain; _ks_wait() orders the first consumer behind it
             cur = torch.cuda.current_stream()
@@ -371,6 +375,20 @@ class Engine:
             else:
                 ops.weights_kslab(f.ks_desc, f.w_lp, f.w_ks)
             f.ks_stamp = stamp
+
+    def _opt_gate(self, names=None, so=None):
+        """FusedAdamW(overlap=True) left its step on its own stream, one event per launch (optim.py): order stream `so` (default: the current one)
+        behind the launch that steps `names` (None: behind all of them).  The launches are in parameter order on one stream, so a later one covers
+        the earlier ones; a name the step did not touch (frozen) needs no launch of its own but rides on the first."""
+        pend = getattr(self.flat, "opt_pending", None)
+        if pend is None:
+            return
+        ev, last = pend["events"], len(pend["events"]) - 1
+        k = last if names is None else max(pend["chunk_of"].get(n, 0) for n in names)
+        so = so if so is not None else torch.cuda.current_stream()
+        if pend["waited"].get(so.cuda_stream, -1) < k:
+            so.wait_event(ev[k])
+            pend["waited"][so.cuda_stream] = k
 
     def _ks_wait(self):
         f = self.flat
@@ -597,6 +615,8 @@ class Engine:
         ln = int(b0 > 0)
         Mr = y1.shape[0]
         k1 = ko = k2 = kh = None
+        if getattr(self.flat, "opt_pending", None) is not None:   # an overlapped optimizer step: this block behind the launch that steps its weights
+            self._opt_gate((pre + "attn.qkv.weight", pre + "mlp.fc2.weight"), None if st is None else (self._so.get(st) or torch.cuda.ExternalStream(st)))
         if self.fp8:
             # The block's four forward GEMM sites (A operands y1, o, y2, h) are shared by the two views' calls: one scale per tensor over the whole batch
             # — the weight gradients contract over both views' tokens at once.  (The step without amax history quantises with the tensor's own maximum,
@@ -808,6 +828,11 @@ class Engine:
         ws, P = self.ws, self.flat.P
         self.st = st = ops.stream()
         B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
+        # an overlapped optimizer step still in flight (FusedAdamW(overlap=True)): the bf16 engine orders every layer behind the launch that steps its
+        # weights (_opt_gate) and lets the rest run under the stem and the first blocks; every other engine starts behind all of it
+        if not (self.T == BF16 and not self.fp8) or debug_opt("opt_gate_all"):
+            self._opt_gate()
+        self._so = {st: torch.cuda.current_stream()}
         self._refresh_lp()
         self._fp8_begin()
         img0 = imgs
@@ -826,6 +851,7 @@ class Engine:
         ws.noise.copy_(noise)
         ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
         ops.patch_gather(img0, img1, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
+        self._opt_gate(("patch_embed.proj.weight", "cls_token"))
         ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
         ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep, st=st)
         self._ks_wait()   # the K-slab weight mirrors (made under the stem on the auxiliary stream) before the first block and before the view streams fork
@@ -854,6 +880,7 @@ class Engine:
         def predictor_fwd(st):
             bn = "predictor.1."
             mod = self.module.predictor[1]
+            self._opt_gate(("predictor.0.weight", "predictor.3.weight"), self._so.get(st))
             ops.rows_gather(ws.emb32, ws.pin, L, Td, N * Td + 1, st=st)
             ops.gemm(ws.pin, self.W("predictor.0.weight"), ws.u, bias=P("predictor.0.bias"), st=st)
             ops.bnrelu_fwd(ws.u, P(bn + "weight"), P(bn + "bias"), ws.r, ws.bn_st[0], ws.bn_st[1], N, L, mod.running_mean, mod.running_var,
@@ -882,6 +909,7 @@ class Engine:
                 ev = torch.cuda.Event()
                 ev.record(stream_obj)
             evs.append(ev)
+            self._opt_gate(("decoder_embed.weight", "mask_token"), stream_obj)
             ops.gemm(lat_op, self.W("decoder_embed.weight"), ws.z[re_], bias=P("decoder_embed.bias"), st=st)
             ops.unshuffle_fwd(ws.z[re_], P("mask_token").view(Dd), P("decoder_pos_embed").view(L + 1, Dd), ws.ids_restore[b0:b0 + nb],
                               ws.dec["x"][0][rd_], nb, L, keep, st=st)
@@ -901,6 +929,7 @@ class Engine:
                     # the longest tail of the forward pass
                     self.aux.wait_event(emb_ready[0])
                     hst = self.aux.cuda_stream
+            self._opt_gate(("decoder_pred.weight",), stream_obj if hst is st else self.aux)
             ops.gemm(ws.emb_lp[rd_], self._w_pred()[: c["P"]], ws.pred[rd_], bias=P("decoder_pred.bias"), st=hst)
             if view_heads:   # (a chunk is a view here: samples [0, N) = the original, [N, 2N) = the crop)
                 ops.recon_loss_fwd(kind, npx, img0 if b0 == 0 else img1, None, ws.pred[rd_], None, ws.rowloss[b0 * L:(b0 + nb) * L], nb, nb,
@@ -928,6 +957,7 @@ class Engine:
             if view_heads and self.has_pred:
                 order = [nch - 1] + list(range(nch - 1))
             lanes = [(st, main)] + [(so.cuda_stream, so) for so in self._fwd_streams[: nch - 1]]
+            self._so.update(lanes)
             gens = [trunk(cuts[k], cuts[k + 1] - cuts[k], lanes[i][0], lanes[i][1], evs) for i, k in enumerate(order)]
 
             def contrastive():
@@ -990,6 +1020,7 @@ class Engine:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 aux.wait_event(ev)
+                self._opt_gate(("predictor.0.weight", "predictor.3.weight"), aux)
                 with torch.cuda.stream(aux):
                     ws.bn_tmp.zero_()
                 ops.pair_loss_bwd(kcd, N * L, Dd, ws.v, (N * L, 0, 0), ws.emb32, (L, Td, 1), ws.one, self._pair_scale(kcd, N * L, Dd), da_lp=ws.dv, st=ast)
@@ -1008,6 +1039,7 @@ class Engine:
         if heads_done:
             torch.cuda.current_stream().wait_event(heads_done[0])
         rscale = 0.5 if (self.views == 2 and c["reduction"] == "mean") else 1.0
+        self._opt_gate()   # (whatever the caller does next on this stream is behind the whole optimizer step)
         ops.loss_finalize(N * L, self.views, ws.rowloss, ws.mask, rscale, ws.losses, st=st, **kw)
         if ssim is not None:
             ops.ssim_apply(kind == "none", self.views, ssim[2], rscale, ws.ssim_terms, ws.losses, st=st)
@@ -1031,6 +1063,7 @@ class Engine:
         ws, P = self.ws, self.flat.P
         self.st = st = ops.stream()
         L, D = c["L"], c["D"]
+        self._opt_gate()
         self._refresh_lp()
         self._ks_wait()
         self._fp8_begin()
@@ -1059,6 +1092,7 @@ class Engine:
             self.ws = Workspace(self, N, keep)
         ws, P = self.ws, self.flat.P
         self.st = st = ops.stream()
+        self._opt_gate()
         self._refresh_lp()
         self._ks_wait()
         self._fp8_begin()
@@ -1117,6 +1151,7 @@ class Engine:
         self._gen_done = sv["gen"]
         P, G = self.flat.P, self.flat.G
         self.st = st = ops.stream()
+        self._opt_gate()   # (the gradient buffer and the gate slot are the optimizer step's inputs)
         N, keep = sv["N"], sv["keep"]
         B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
         self.main = torch.cuda.current_stream()

@@ -6,6 +6,7 @@ checkpoints stay interchangeable (util/misc.py:364-370).  One HIP launch per par
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -24,12 +25,22 @@ def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
 
 class FusedAdamW(torch.optim.Optimizer):
     TILE = 4096
+    CHUNKS = int(os.environ.get("CSMAE_OPT_CHUNKS", "16"))   # overlap mode: launches per parameter group, one event each ...
+    CHUNK_MIN_TILES = 256  # ... of at least a million elements (the bias / norm group stays one launch)
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, overlap=False):
+        """`overlap=True`: the step is enqueued on the optimizer's own stream, in `CHUNKS` launches per group in parameter order, and returns with the
+        CURRENT stream NOT ordered behind it: the next forward pass of the model's engine orders each layer behind the chunk that steps its weights
+        (Engine._opt_gate), so the optimizer's HBM-bound 0.7 ms run under the stem and the first encoder blocks instead of alone on the chip.  Whoever
+        reads parameters or optimizer state on another stream before that forward pass calls `join()` first (state_dict() does; zero_grad(set_to_none=
+        False) does).  Off by default: `step()` then is ordered on the current stream like torch.optim's."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat = None
         self._plans = {}
         self._m = self._v = None
+        self.overlap = bool(overlap)
+        self._ostream = None
+        self._oevents = []
 
     def _bind(self):
         from .engine import FlatParams
@@ -92,8 +103,29 @@ class FusedAdamW(torch.optim.Optimizer):
                                     t8=torch.tensor(t8, dtype=torch.long, device=dev).reshape(-1, 6) if t8 else None, f8_names=f8_names,
                                     ks=torch.tensor(ks, dtype=torch.long, device=dev).reshape(-1, 3) if has_ks else None,
                                     ks_names={flat._by_id[id(q)] for q in params} & set(ks_names) if has_ks else set(),
-                                    step=self._common_step(params))
+                                    step=self._common_step(params), chunks=self._chunks(flat, params, offs, f8_names))
         return self._plans[key]
+
+    def _chunks(self, flat, params, offs, skip):
+        """Overlap mode: the plan's tiles cut into up to CHUNKS contiguous launches on parameter boundaries -> [(tile_lo, tile_hi, names)]."""
+        bounds, t = [], 0   # (first tile, name) per parameter, in plan order
+        for p in params:
+            name = flat._by_id[id(p)]
+            if name in skip:
+                continue
+            bounds.append((t, name))
+            t += -(-flat.slot_of(p)[1] // self.TILE)
+        assert t == len(offs)
+        nch = min(self.CHUNKS, max(1, t // self.CHUNK_MIN_TILES))
+        per, out = max(1, -(-t // nch)), []
+        for t0, name in bounds:
+            if not out or (t0 - out[-1][0] >= per and len(out) < nch):
+                out.append([t0, t, [name]])
+                if len(out) > 1:
+                    out[-2][1] = t0
+            else:
+                out[-1][2].append(name)
+        return [tuple(c) for c in out]
 
     def _common_step(self, params):
         """torch.optim.AdamW counts steps per parameter; one launch per group needs one bias correction.  Parameters of a group that
@@ -126,6 +158,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ks_before = getattr(flat, "ks_stamp", None) is not None and flat.ks_stamp == (flat.lp_stamp, flat.raw_writes)   # K-slab mirror consistent on entry
         ks_written, f8_written = set(), set()
         f8_before = getattr(flat, "w8_stamp", None) is not None and flat.w8_stamp == (flat.version_stamp(), flat.raw_writes)   # fp8 mirrors consistent on entry
+        todo = []
         for gi, group in enumerate(self.param_groups):
             plan = self._plan(gi, group, flat)
             params = plan["params"]
@@ -135,17 +168,39 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.grad.data_ptr() - g0 != flat.slot_of(p)[0] * 4:
                     off, n, _ = flat.slot_of(p)
                     flat.g[off:off + n].view(p.shape).copy_(p.grad)
-            plan["step"] += 1
-            step = plan["step"]
             wd = float(group["weight_decay"])
             if wd != plan["wd_host"]:
                 plan["wd"].fill_(wd)
                 plan["wd_host"] = wd
+            todo.append((group, plan, wd))
+        # overlap mode (see __init__): the launches go to the optimizer's stream, behind everything enqueued on the current one (the backward pass,
+        # the gradient exchange's join); one event per launch for the engine's next forward pass to order its layers behind
+        ov = (self.overlap and flat.p.is_cuda and ops._timer is None and not any(plan["t8"] is not None for _, plan, _ in todo)
+              and not os.environ.get("CSMAE_OPT_MAIN"))
+        self.join()                   # (a previous overlapped step nobody ordered behind: this one's launches must be; no-op otherwise)
+        st, pending = None, None
+        if ov:
+            if self._ostream is None:
+                self._ostream = torch.cuda.Stream()
+            self._ostream.wait_stream(torch.cuda.current_stream())
+            st = self._ostream.cuda_stream
+            pending = dict(events=[], chunk_of={}, waited={}, stream=self._ostream)
+        for group, plan, wd in todo:
+            plan["step"] += 1
+            step = plan["step"]
             b1, b2 = group["betas"]
             ks_ok = plan["ks"] is not None and flat.w_lp is not None and getattr(flat, "w_ks", None) is not None
             if plan["off"].numel():
-                ops.adamw(plan["off"], plan["cnt"], plan["wd"], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, p_lp=flat.w_lp,
-                          gate=flat.gate, tile_ks=plan["ks"] if ks_ok else None, p_ks=flat.w_ks if ks_ok else None)
+                for lo, hi, names in (plan["chunks"] if ov else [(0, plan["off"].numel(), ())]):
+                    ops.adamw(plan["off"][lo:hi], plan["cnt"][lo:hi], plan["wd"][lo:hi], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step,
+                              p_lp=flat.w_lp, gate=flat.gate, tile_ks=plan["ks"][lo:hi] if ks_ok else None, p_ks=flat.w_ks if ks_ok else None, st=st)
+                    if ov:
+                        k = len(pending["events"])
+                        while len(self._oevents) <= k:
+                            self._oevents.append(torch.cuda.Event())
+                        self._oevents[k].record(self._ostream)
+                        pending["events"].append(self._oevents[k])
+                        pending["chunk_of"].update((n, k) for n in names)
             if plan["t8"] is not None:
                 flat.w8_amax[1].zero_()
                 ops.adamw_fp8(plan["t8"], wd, flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, flat.w_lp, flat.gate, flat.w8, flat.w8t,
@@ -157,6 +212,8 @@ class FusedAdamW(torch.optim.Optimizer):
             if ks_ok:
                 ks_written |= plan["ks_names"]
             self._dirty_steps = True
+        if ov and pending["events"]:
+            flat.opt_pending = pending
         if ks_before and ks_written and ks_written == set(flat.ks_names):   # every K-slab mirror was re-written by the launches above: still consistent
             flat.ks_stamp = (flat.lp_stamp, flat.raw_writes)
         if f8_written:
@@ -165,6 +222,22 @@ class FusedAdamW(torch.optim.Optimizer):
                 flat.w8_stamp = (flat.version_stamp(), flat.raw_writes)
             else:
                 flat.w8_stamp = None
+
+    def join(self):
+        """Order the current stream behind an overlapped step still in flight (no host synchronisation).  No-op otherwise."""
+        flat = self._flat
+        pend = getattr(flat, "opt_pending", None) if flat is not None else None
+        if pend is not None:
+            cur = torch.cuda.current_stream()
+            last = len(pend["events"]) - 1
+            if pend["waited"].get(cur.cuda_stream, -1) < last:
+                cur.wait_event(pend["events"][last])
+                pend["waited"][cur.cuda_stream] = last
+
+    def zero_grad(self, set_to_none: bool = True):
+        if not set_to_none:
+            self.join()   # (the zero-fill runs on the current stream: behind the step's reads of the gradients)
+        return super().zero_grad(set_to_none=set_to_none)
 
     def _sync_steps(self):
         """torch's per-parameter `step` entries are refreshed lazily (state_dict / checkpointing), not 250 tensors per step."""
@@ -175,6 +248,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._dirty_steps = False
 
     def state_dict(self):
+        self.join()
         self._sync_steps()
         return super().state_dict()
 

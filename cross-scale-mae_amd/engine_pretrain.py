@@ -86,6 +86,8 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
         if data_iter_step % PRINT_FREQ == 0 or data_iter_step == n_iters - 1:
             drain()  # exactly the iterations on which log_every prints the meters
     drain()
+    if hasattr(optimizer, "join"):
+        optimizer.join()   # (FusedAdamW(overlap=True): whatever reads the weights after this epoch — checkpointing, evaluation — is behind the last step)
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

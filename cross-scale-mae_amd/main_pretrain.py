@@ -194,7 +194,8 @@ def main(args):
         model = DataParallel(model, device_ids=[args.gpu], find_unused_parameters=True,
                              comm_dtype={"auto": "auto", "bf16": torch.bfloat16, "fp32": None}[args.grad_comm_dtype])
         model_without_ddp = model.module
-    optimizer = FusedAdamW(add_weight_decay(model_without_ddp, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))
+    # overlap: the step is enqueued on its own stream and the next forward pass orders each layer behind the launch that steps its weights (optim.py)
+    optimizer = FusedAdamW(add_weight_decay(model_without_ddp, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), overlap=True)
     print(optimizer)
     loss_scaler = NativeScaler()
     misc.load_model(args=args, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)

@@ -207,6 +207,46 @@ def test_micro_two_fused_adamw_steps_fp32():
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and len(sd["param_groups"]) == 2
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_overlapped_optimizer_step_matches_ordered_step(dtype, monkeypatch):
+    """FusedAdamW(overlap=True): the step on its own stream in several launches, the next forward pass ordering each layer behind the launch that steps
+    its weights (Engine._opt_gate) — same losses, weights and moments as the step ordered on the current stream."""
+    from csmae_hip.optim import FusedAdamW, add_weight_decay
+    monkeypatch.setattr(FusedAdamW, "CHUNK_MIN_TILES", 1)
+    d = load("model_micro.npz")
+    imgs = T(d["imgs"]).cuda()
+    runs = []
+    for overlap in (False, True):
+        m = build("MAE_ViT_MsLdCeCd", micro_sd(d))
+        m.compute_dtype = dtype
+        opt = FusedAdamW(add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95), overlap=overlap)
+        losses = []
+        for s in range(5):
+            m._test_draws = draws(d, f"cecd_s{s % 2}")
+            opt.zero_grad(set_to_none=(s != 3))
+            loss, _, _ = m(imgs, mask_ratio=0.75)
+            loss.backward()
+            opt.step()
+            losses.append(loss)
+            if overlap and s >= 1:
+                f = next(iter(m._engines.values())).flat
+                assert f.opt_pending is not None and len(f.opt_pending["events"]) > 2, "the overlapped step did not split into launches"
+            if s == 2:
+                opt.state_dict()   # (orders the current stream behind the step in flight)
+        opt.join()
+        runs.append(([float(x) for x in losses], {n: p.detach().clone() for n, p in m.named_parameters()}, opt.state_dict()))
+    # (a few gradients are atomic sums — mask_token, cls_token — so two runs of ONE schedule already differ in the last bits: the comparison is to
+    # 2e-6 absolute, three orders below one AdamW update at this learning rate — what a layer reading its weights before their step would show)
+    (la, pa, sa), (lb, pb, sb) = runs
+    np.testing.assert_allclose(la, lb, rtol=2e-6)
+    for n in pa:
+        if not n.endswith("attn.qkv.bias"):   # (zero-gradient key biases: AdamW normalises their rounding noise to full-size updates, see test_oracle_golden)
+            assert torch.allclose(pa[n], pb[n], rtol=1e-5, atol=2e-6), (n, float((pa[n] - pb[n]).abs().max()))
+    for k, st in sa["state"].items():
+        ma, mb = st["exp_avg"], sb["state"][k]["exp_avg"]
+        assert float((ma - mb).abs().max()) <= 1e-3 * float(ma.abs().max()) + 1e-12 and float(st["step"]) == float(sb["state"][k]["step"]), k
+
+
 @pytest.mark.parametrize("loss", ["l2", "mae", "l1", "normpix_mean"])
 def test_loss_options_fp32(loss):
     d = load("model_micro.npz")

@@ -20,7 +20,7 @@ python tools/step_timeline.py $(find /tmp/prof_$tag -name '*.db' | head -1) > $o
 # under API tracing the host falls behind the GPU, so that run's gaps are the profiler's)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --marker-trace --hip-runtime-trace -d /tmp/profm_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing --steps 6 --warmup 2 > /dev/null 2>&1 )
 python tools/step_timeline.py $(find /tmp/profm_$tag -name '*.db' | head -1) --phases-only >> $out/step_timeline.txt 2>&1
-( cd /tmp && CSMAE_DW_MAIN=1 CSMAE_FWD_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profs_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
+( cd /tmp && CSMAE_DW_MAIN=1 CSMAE_FWD_ONE_STREAM=1 CSMAE_OPT_MAIN=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profs_$tag -o r -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1 )
 python tools/rocpd_stats.py $(find /tmp/profs_$tag -name '*.db' | head -1) $out/step_serialised_kernel_stats.txt > /dev/null
 bash tools/roofline_round.sh $tag > /dev/null 2>&1   # per-kernel HBM GB/s + MFMA utilisation (kernel_roofline.txt) and the HBM traffic table / pmc_traffic.json
 for p in large large4; do timeout 600 python bench.py --preset $p --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out/bench_presets.txt; done
