@@ -27,7 +27,7 @@ __device__ __forceinline__ void fp8_amax_body(long long rows, int cols, const T*
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    atomicMax(reinterpret_cast<unsigned*>(amax) + (blockIdx.x & (FP8_SLOTS - 1)), __float_as_uint(m));   // (non-negative floats order like their bit patterns)
+    amax_publish(amax + (blockIdx.x & (FP8_SLOTS - 1)), m);
   }
 }
 template <typename T>
@@ -70,7 +70,7 @@ __device__ __forceinline__ void fp8_quant_body(long long rows, int cols, const T
       __syncthreads();
       if (threadIdx.x == 0) {
         seen = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        if (seen > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_next) + (blockIdx.x & (FP8_SLOTS - 1)), __float_as_uint(seen));
+        amax_publish(amax_next + (blockIdx.x & (FP8_SLOTS - 1)), seen);
       }
     }
   } else {  // 64 x 64 tiles through LDS: reads along source rows, writes along destination rows

@@ -359,7 +359,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   }
   if (emit) {   // this wave's share of the new amax: one atomic per wave, spread over the 64 slots
     qseen = wave_max64(qseen);
-    if (lane == 0 && qseen > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q_amax_next) + ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 63), __float_as_uint(qseen));
+    if (lane == 0) amax_publish(p.q_amax_next + ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 63), qseen);
   }
 }
 

@@ -138,13 +138,16 @@ __global__ __launch_bounds__(256, NV == 3 ? 4 : (NV == 2 ? 5 : 1)) void ln_bwd_k
 // The throughput mode's instance (dy, x, dres_in, dx_out all bf16, no second copy) holding a row's three inputs PACKED (8 bytes per lane and load) through
 // the two reductions and unpacking them at each use: 54 instead of 90 live registers at D = 768, i.e. six instead of four waves per SIMD — a wave handles one
 // row at a time and is bound by its row's HBM round trip, so rows in flight per CU are what the kernel's bandwidth consists of (3.7 TB/s alone at four waves).
-template <int NV, int MINW>
+template <int NV, int MINW, bool EMIT>
 __global__ __launch_bounds__(256, MINW) void ln_bwd_bf16_kernel(long long M, int D, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma, const bf16_t* __restrict__ dres_in,
-                                                                bf16_t* __restrict__ dx_out, float* __restrict__ part) {
+                                                                bf16_t* __restrict__ dx_out, float* __restrict__ part, Fp8Emit em) {
   __shared__ float red[4 * 64 * 4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nv = D >> 2;
+  // EMIT (fp8 mode): the outgoing gradient also leaves as fp8 bytes (the next product's operand), scaled with the previous step's maximum (common.h Fp8Emit)
+  float qmax = 0.f, qseen = 0.f;
+  const float qscale = EMIT ? fp8_emit_scale(em, lane, qmax) : 1.f;
   f4_t gm[NV], ag[NV], ab[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256, MINW) void ln_bwd_bf16_kernel(long long M, int
   const brsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, (int)(unsigned)bytes, 0x00020000);
   const brsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dres_in ? dres_in : dy), 0, dres_in ? (int)(unsigned)bytes : 0, 0x00020000);
   const brsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(dx_out, 0, (int)(unsigned)bytes, 0x00020000);
+  const brsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(EMIT ? em.q : (unsigned char*)dx_out, 0, EMIT ? (int)(unsigned)(bytes >> 1) : 0, 0x00020000);
   for (long long row = (long long)blockIdx.x * 4 + w; row < M; row += (long long)gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
     const unsigned voff = (unsigned)((row * D + lane * 4) * 2);
@@ -191,9 +195,11 @@ __global__ __launch_bounds__(256, MINW) void ln_bwd_bf16_kernel(long long M, int
       const f4_t xh = up(rx[i]) * rs + c0, g = up(rd[i]) * gm[i];
       const f4_t o4 = (g - s1 - xh * s2) * rs + up(rr[i]);
       __builtin_amdgcn_raw_buffer_store_b64(u2_t{pack2bf(o4[0], o4[1]), pack2bf(o4[2], o4[3])}, rO, o, 0, 0);
+      if (EMIT) __builtin_amdgcn_raw_buffer_store_b32(fp8_pack4(lane + i * 64 < nv ? o4 : f4_t{0.f, 0.f, 0.f, 0.f}, qscale, qmax, em.fmt, qseen), rQ, o >> 1, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (EMIT) fp8_emit_amax(em, qseen, lane);
   if (!part) return;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -297,10 +303,11 @@ static void ln_bwd_launch(long long M, int D, const void* dy, const void* x, con
 #define LNB(NVV) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TLP, NVV>), grid, block, 0, st, M, D, (const TDY*)dy, (const TX*)x, mean, rstd, gamma, (const TX*)dres_in, (TX*)dx_out, (TLP*)dx_lp, dgamma, dbeta, part, em)
   // the all-bf16 stream with deferred parameter gradients and no fp8 copy (every block LayerNorm of the bf16 step): the packed-register instance
   static const bool no_packed = csmae_debug_opt("ln_bwd_unpacked") != nullptr;   // A/B aid
-  if (std::is_same<TDY, bf16_t>::value && std::is_same<TX, bf16_t>::value && !dx_lp && !dgamma && part && !em.q && !no_packed && D % 4 == 0 && nv >= 2 && nv <= 4 &&
+  if (std::is_same<TDY, bf16_t>::value && std::is_same<TX, bf16_t>::value && !dx_lp && !dgamma && part && !no_packed && D % 4 == 0 && nv >= 2 && nv <= 5 &&
       (M + 4) * (long long)D * 2 < 0xFFFFFFF0ll) {
-#define LNBP(NVV, MW) hipLaunchKernelGGL((ln_bwd_bf16_kernel<NVV, MW>), grid, block, 0, st, M, D, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres_in, (bf16_t*)dx_out, part)
-    if (nv == 2) LNBP(2, 6); else if (nv == 3) LNBP(3, 5); else LNBP(4, 4);
+#define LNBP(NVV, MW, EM) hipLaunchKernelGGL((ln_bwd_bf16_kernel<NVV, MW, EM>), grid, block, 0, st, M, D, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres_in, (bf16_t*)dx_out, part, em)
+    if (em.q) { if (nv == 2) LNBP(2, 6, true); else if (nv == 3) LNBP(3, 5, true); else if (nv == 4) LNBP(4, 4, true); else LNBP(5, 3, true); }
+    else { if (nv == 2) LNBP(2, 6, false); else if (nv == 3) LNBP(3, 5, false); else if (nv == 4) LNBP(4, 4, false); else LNBP(5, 3, false); }
 #undef LNBP
     return;
   }

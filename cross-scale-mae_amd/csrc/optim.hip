@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void adamw_f8_kernel(const long long* __restri
   __syncthreads();
   if (threadIdx.x == 0) {
     seen = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (seen > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_next) + (long long)wi * 64 + (blockIdx.x & 63), __float_as_uint(seen));
+    amax_publish(amax_next + (long long)wi * 64 + (blockIdx.x & 63), seen);
   }
 }
 extern "C" int csmae_adamw_fp8(long long ntiles, const long long* tile8, float weight_decay, float* p, const float* g, float* m, float* v, float lr, float beta1,
