@@ -323,7 +323,7 @@ class Engine:
         t = self.flat.P(name)
         return t.view(t.shape[0], -1) if t.dim() > 1 else t
 
-    def _refresh_lp(self):
+    def _refresh_lp(self, lazy_pads=False):
         """Bring the bf16 weight mirror up to date.  FusedAdamW writes the mirror in the same kernel that steps the fp32 master (through
         raw pointers: no version counter moves), so a full recast (0.7 GB of HBM traffic for ViT-B) is only needed when somebody else
         has written the parameters in place — torch.optim, load_state_dict, manual edits.  Those bump the *Parameters'* version
@@ -338,12 +338,18 @@ class Engine:
             self._opt_gate()
             ops.cast_bf16(self.flat.p, self.flat.w_lp)
             self.flat.lp_stamp = stamp
-        if self.Pp != self.cfg["P"]:
-            P = self.cfg["P"]
+        if self.Pp != self.cfg["P"] and not lazy_pads:
             self._opt_gate()
-            self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
-            self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
+            self._refresh_pads(True, True)
         self._refresh_ks()
+
+    def _refresh_pads(self, pe, pred):
+        """Zero-padded bf16 copies of the two weights whose patch dimension is not a multiple of the GEMM's K step (patch 14: P = 588), from the masters."""
+        P = self.cfg["P"]
+        if pe:
+            self.w_pe_pad[:, :P].copy_(self.flat.P("patch_embed.proj.weight").view(self.cfg["D"], P))
+        if pred:
+            self.w_pred_pad[:P].copy_(self.flat.P("decoder_pred.weight"))
 
     def _refresh_ks(self):
         """K-slab mirrors of the blocks' Linear weights (csmae.h csmae_gemm_ks: the forward products' B operand on the two-workgroups-per-CU
@@ -432,6 +438,7 @@ class Engine:
         stamp = (f.version_stamp(), f.raw_writes)
         if f.w8_stamp == stamp and not debug_opt("fp8_requant"):
             return             # the mirrors were written by the optimizer step itself: nothing has touched the masters since
+        self._opt_gate()
         f.w8_amax[0].zero_()
         ops.fp8_weights(f.w8_desc, f.p, f.w8, f.w8t, f.w8_amax[0], f.w8_dq)   # (one batched amax + two batched quantise launches instead of four per weight)
         f.w8_stamp = stamp
@@ -830,11 +837,14 @@ class Engine:
         B2, Te, Td, L, D, Dd = ws.B2, ws.Te, ws.Td, c["L"], c["D"], c["Dd"]
         # an overlapped optimizer step still in flight (FusedAdamW(overlap=True)): the bf16 engine orders every layer behind the launch that steps its
         # weights (_opt_gate) and lets the rest run under the stem and the first blocks; every other engine starts behind all of it
-        if not (self.T == BF16 and not self.fp8) or debug_opt("opt_gate_all"):
+        fine = self.T == BF16 and not debug_opt("opt_gate_all")
+        if not fine:
             self._opt_gate()
         self._so = {st: torch.cuda.current_stream()}
-        self._refresh_lp()
+        self._refresh_lp(lazy_pads=fine)
         self._fp8_begin()
+        pads = fine and self.Pp != c["P"]   # (patch 14: the padded copies of the stem's and the prediction head's weights are re-made below, each behind its own launch of the step)
+        pred_pad_ev = None
         img0 = imgs
         two = self.views == 2 and ops._timer is None and not os.environ.get("CSMAE_FWD_ONE_STREAM")
         if self.fp8 and not ws.fp8_hist:
@@ -852,6 +862,8 @@ class Engine:
         ops.mask_sort(ws.noise, keep, ws.ids_restore, ws.mask, ws.ids_keep, st=st)
         ops.patch_gather(img0, img1, ws.ids_keep, ws.a_pe, N, c["C"], c["S"], c["p"], keep, st=st)
         self._opt_gate(("patch_embed.proj.weight", "cls_token"))
+        if pads:
+            self._refresh_pads(True, False)
         ops.gemm(ws.a_pe, self._w_pe(), ws.tok, bias=P("patch_embed.proj.bias"), st=st)
         ops.embed_assemble(ws.tok, P("encoder_pos_embed").view(L + 1, D), P("cls_token").view(D), ws.ids_keep, ws.enc["x"][0], B2, keep, st=st)
         self._ks_wait()   # the K-slab weight mirrors (made under the stem on the auxiliary stream) before the first block and before the view streams fork
@@ -863,6 +875,13 @@ class Engine:
         if self.aux is None:
             self.aux = torch.cuda.Stream()
         ce_done = None
+        if pads:   # the prediction head's padded weight on the auxiliary stream, behind the launch that steps decoder_pred (and behind the last backward pass, which read it)
+            self.aux.wait_stream(main)
+            self._opt_gate(("decoder_pred.weight",), self.aux)
+            with torch.cuda.stream(self.aux):
+                self._refresh_pads(False, True)
+            pred_pad_ev = torch.cuda.Event()
+            pred_pad_ev.record(self.aux)
 
         kind, npx = c["loss"], c["norm_pix"]
         ssim = SSIM_KINDS.get(kind)
@@ -930,6 +949,8 @@ class Engine:
                     self.aux.wait_event(emb_ready[0])
                     hst = self.aux.cuda_stream
             self._opt_gate(("decoder_pred.weight",), stream_obj if hst is st else self.aux)
+            if pred_pad_ev is not None:
+                (stream_obj if hst is st else self.aux).wait_event(pred_pad_ev)
             ops.gemm(ws.emb_lp[rd_], self._w_pred()[: c["P"]], ws.pred[rd_], bias=P("decoder_pred.bias"), st=hst)
             if view_heads:   # (a chunk is a view here: samples [0, N) = the original, [N, 2N) = the crop)
                 ops.recon_loss_fwd(kind, npx, img0 if b0 == 0 else img1, None, ws.pred[rd_], None, ws.rowloss[b0 * L:(b0 + nb) * L], nb, nb,

@@ -5,6 +5,7 @@ timm `add_weight_decay` grouping); `state_dict()` keeps torch's per-parameter la
 checkpoints stay interchangeable (util/misc.py:364-370).  One HIP launch per parameter group reads p, g, m, v once (28 B/param)."""
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 
@@ -76,7 +77,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._sync_steps()
             for old in [k for k in self._plans if k[0] == gi]:  # the group's active set changed: its old plan (and counter) is superseded
                 del self._plans[old]
-            offs, cnts, params, ks, t8, f8_names = [], [], [], [], [], set()
+            offs, cnts, params, ks, t8, f8_names, b8 = [], [], [], [], [], set(), []
             ks_names = getattr(flat, "ks_names", None) if getattr(flat, "w_ks", None) is not None else None
             for p in group["params"]:
                 if p.grad is None:
@@ -86,6 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 name = flat._by_id[id(p)]
                 if f8 and name in flat.w8_idx and len(shape) == 2 and shape[0] % 64 == 0 and shape[1] % 64 == 0:
                     wi = flat.w8_idx[name]
+                    b8.append((len(t8), name))
                     t8.extend((off, shape[0], shape[1], n0, k0, wi) for n0 in range(0, shape[0], 64) for k0 in range(0, shape[1], 64))
                     f8_names.add(name)
                     continue
@@ -103,7 +105,8 @@ class FusedAdamW(torch.optim.Optimizer):
                                     t8=torch.tensor(t8, dtype=torch.long, device=dev).reshape(-1, 6) if t8 else None, f8_names=f8_names,
                                     ks=torch.tensor(ks, dtype=torch.long, device=dev).reshape(-1, 3) if has_ks else None,
                                     ks_names={flat._by_id[id(q)] for q in params} & set(ks_names) if has_ks else set(),
-                                    step=self._common_step(params), chunks=self._chunks(flat, params, offs, f8_names))
+                                    step=self._common_step(params), chunks=self._chunks(flat, params, offs, f8_names),
+                                    chunks8=self._cut(b8, len(t8), self.CHUNKS, 1))
         return self._plans[key]
 
     def _chunks(self, flat, params, offs, skip):
@@ -116,7 +119,11 @@ class FusedAdamW(torch.optim.Optimizer):
             bounds.append((t, name))
             t += -(-flat.slot_of(p)[1] // self.TILE)
         assert t == len(offs)
-        nch = min(self.CHUNKS, max(1, t // self.CHUNK_MIN_TILES))
+        return self._cut(bounds, t, self.CHUNKS, self.CHUNK_MIN_TILES)
+
+    @staticmethod
+    def _cut(bounds, t, chunks, min_tiles):
+        nch = min(chunks, max(1, t // min_tiles))
         per, out = max(1, -(-t // nch)), []
         for t0, name in bounds:
             if not out or (t0 - out[-1][0] >= per and len(out) < nch):
@@ -175,8 +182,7 @@ class FusedAdamW(torch.optim.Optimizer):
             todo.append((group, plan, wd))
         # overlap mode (see __init__): the launches go to the optimizer's stream, behind everything enqueued on the current one (the backward pass,
         # the gradient exchange's join); one event per launch for the engine's next forward pass to order its layers behind
-        ov = (self.overlap and flat.p.is_cuda and ops._timer is None and not any(plan["t8"] is not None for _, plan, _ in todo)
-              and not os.environ.get("CSMAE_OPT_MAIN"))
+        ov = self.overlap and flat.p.is_cuda and ops._timer is None and not os.environ.get("CSMAE_OPT_MAIN")
         self.join()                   # (a previous overlapped step nobody ordered behind: this one's launches must be; no-op otherwise)
         st, pending = None, None
         if ov:
@@ -195,16 +201,15 @@ class FusedAdamW(torch.optim.Optimizer):
                     ops.adamw(plan["off"][lo:hi], plan["cnt"][lo:hi], plan["wd"][lo:hi], flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step,
                               p_lp=flat.w_lp, gate=flat.gate, tile_ks=plan["ks"][lo:hi] if ks_ok else None, p_ks=flat.w_ks if ks_ok else None, st=st)
                     if ov:
-                        k = len(pending["events"])
-                        while len(self._oevents) <= k:
-                            self._oevents.append(torch.cuda.Event())
-                        self._oevents[k].record(self._ostream)
-                        pending["events"].append(self._oevents[k])
-                        pending["chunk_of"].update((n, k) for n in names)
+                        self._mark(pending, names)
             if plan["t8"] is not None:
-                flat.w8_amax[1].zero_()
-                ops.adamw_fp8(plan["t8"], wd, flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, flat.w_lp, flat.gate, flat.w8, flat.w8t,
-                              flat.w8_amax[0], flat.w8_amax[1], flat.w8_dq)
+                with torch.cuda.stream(self._ostream) if ov else contextlib.nullcontext():
+                    flat.w8_amax[1].zero_()
+                for lo, hi, names in (plan["chunks8"] if ov else [(0, plan["t8"].shape[0], ())]):
+                    ops.adamw_fp8(plan["t8"][lo:hi], wd, flat.p, flat.g, self._m, self._v, group["lr"], b1, b2, group["eps"], step, flat.w_lp, flat.gate, flat.w8, flat.w8t,
+                                  flat.w8_amax[0], flat.w8_amax[1], flat.w8_dq, st=st)
+                    if ov:
+                        self._mark(pending, names)
                 f8_written |= plan["f8_names"]
             # the kernel wrote the masters (and the bf16 mirror) behind torch's version counters: mirrors derived from it (fp8) are stale.  The K-slab
             # mirror is not, when this launch wrote it for every weight that has one and it was consistent before (Engine._refresh_ks's stamp)
@@ -222,6 +227,15 @@ class FusedAdamW(torch.optim.Optimizer):
                 flat.w8_stamp = (flat.version_stamp(), flat.raw_writes)
             else:
                 flat.w8_stamp = None
+
+    def _mark(self, pending, names):
+        """An event behind the launch just enqueued on the optimizer's stream; `names` = the parameters it stepped."""
+        k = len(pending["events"])
+        while len(self._oevents) <= k:
+            self._oevents.append(torch.cuda.Event())
+        self._oevents[k].record(self._ostream)
+        pending["events"].append(self._oevents[k])
+        pending["chunk_of"].update((n, k) for n in names)
 
     def join(self):
         """Order the current stream behind an overlapped step still in flight (no host synchronisation).  No-op otherwise."""

@@ -552,6 +552,46 @@ def _fullsize_case(tag, dtypes):
     return m
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, "fp8"])
+def test_overlapped_optimizer_step_patch14_bf16_and_fp8(dtype):
+    """FusedAdamW(overlap=True) at the ViT-H/14 geometry: the fp8 engine (block weights stepped through csmae_adamw_fp8 in launches of their own, the fp8
+    mirrors written by them) and the padded copies of the stem's / the prediction head's weights (patch 14), each ordered behind its own launch of the step.
+    Four steps against the step ordered on the current stream: same losses; weights equal up to the few elements whose Adam update amplifies rounding noise
+    (a layer that read its weights before their step would move every element of the layers behind it by about the learning rate)."""
+    import fullsize_util as F
+    from csmae_hip.optim import FusedAdamW, add_weight_decay
+    tag = "vith14_224"
+    meta, d = F.load(tag)
+    imgs = F.inputs(tag, meta).cuda()
+    noise, box = [T(d["noise0"]), T(d["noise1"])], tuple(meta["box"])
+    lr, runs = 1e-4, []
+    for overlap in (False, True):
+        m = F.seeded_model(meta).cuda().train()
+        m.compute_dtype = dtype
+        opt = FusedAdamW(add_weight_decay(m, 0.05), lr=lr, betas=(0.9, 0.95), overlap=overlap)
+        losses = []
+        for s in range(4):
+            m._test_draws = dict(noise=noise, box=box)
+            opt.zero_grad()
+            loss, _, _ = m(imgs, mask_ratio=0.75)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        f = next(iter(m._engines.values())).flat
+        pend = getattr(f, "opt_pending", None)
+        assert (pend is not None and len(pend["events"]) > 8) == overlap
+        opt.join()
+        runs.append(([float(x) for x in losses], {n: p.detach().clone() for n, p in m.named_parameters()}))
+        del m, opt
+    (la, pa), (lb, pb) = runs
+    np.testing.assert_allclose(la, lb, rtol=2e-4 if dtype == "fp8" else 2e-5)
+    assert la[-1] < la[0]
+    for n in pa:
+        if not n.endswith("attn.qkv.bias"):
+            far = float(((pa[n] - pb[n]).abs() > 0.2 * lr).float().mean())
+            assert far < 0.01, (n, far)
+
+
 FP8_LOSS_RTOL = 1e-2     # fp8 MFMA path (e4m3 activations / weights, e5m2 gradients, per-tensor scales) vs the reference, total loss (measured 1e-3 .. 2e-3)
 FP8_GRAD_COS = 0.98      # cosine of every parameter gradient against the oracle's (2-bit-mantissa gradients in the dX products; measured worst 0.989, median 0.994)
 
