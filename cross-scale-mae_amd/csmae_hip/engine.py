@@ -459,6 +459,15 @@ class Engine:
             self._fp8_site = 0
             self._fp8_blk, self._fp8_kept = {}, {}
 
+    def _fp8_lean(self, Dm, T, H):
+        """fp8 mode in its steady state: every consumer of y1 / y2 (the LayerNorm outputs), h (fc1's GELU output), dpre (fc2's dX x gelu') and dqkv reads the
+        fp8 copy its producer emits — the next product, the weight-gradient products (csmae_gemm_dw_group_fp8), the bias gradients (column sums of the fp8
+        bytes) — so the bf16 tensors are not written at all: 13 of a block's token x width matrices per step (ViT-H/14 at 256 per GPU: 49 GB of stores).
+        Exactly the conditions under which _block_bwd takes the fp8 weight-gradient path (it raises if it finds otherwise)."""
+        ws = self.ws
+        return bool(self.fp8 and self.fp8_dw and ws.fp8_hist and self._fp8_fuse and self._fp8_fuse_lnb and self._fp8_fuse_attn and self._dw_mode == "half"
+                    and self.res_dtype == torch.bfloat16 and Dm >= 256 and Dm % 16 == 0 and ops.attn_resident(ops.BF16, T, Dm // H) and not debug_opt("fp8_keep_bf16"))
+
     def _fp8_alloc(self):
         """Next GEMM-site index of the step (None outside fp8 mode).  The order of the calls is the same every step: that is what ties
         a site to the amax it recorded one step earlier."""
@@ -483,7 +492,8 @@ class Engine:
             return None
         return (dst, fmt, ws.fp8_amax[1][site], ws.fp8_amax[0][site], ws.fp8_dq[site:site + 1])
 
-    def _mm(self, a, name, out, *, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None, lane=0, site=None, emit_site=None, a8=None, emit_dst=None):
+    def _mm(self, a, name, out, *, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, resid=None, st=None, lane=0, site=None, emit_site=None, a8=None, emit_dst=None,
+            skip_out=False):
         """out = a W^T (forward) / a W (trans_b: dX) for a block weight `name`, through the bf16 / fp32 GEMM or, in fp8 mode, through
         quantise(a) + the fp8 GEMM.  `lane` picks the fp8 staging buffers (the two forward streams quantise concurrently).
         `emit_site`: this product's output is the A operand of GEMM site `emit_site` — with delayed scaling the epilogue writes its fp8
@@ -514,7 +524,7 @@ class Engine:
         emit = self._emit_to(emit_site, emit_dst, fmt) if emit_dst is not None else self._emit(emit_site, ws.q_b[lane], out.shape[0], out.shape[1], fmt)
         wi = f.w8_idx[name]
         return ops.gemm_fp8(a8, b8, out, ws.fp8_dq[k:k + 1], f.w8_dq[wi:wi + 1], a_fmt=fmt, bias=bias, epilogue=epilogue, aux=aux, resid=resid,
-                            emit=emit, st=st)
+                            emit=emit, skip_out=skip_out and emit is not None, st=st)
 
     @staticmethod
     def _splitk(m_out, n_out, k_red, tile, ktile):
@@ -635,9 +645,10 @@ class Engine:
         keep8 = self.fp8 and self.fp8_dw   # the fp8 copies go to their per-layer homes (the dW products read them in the backward pass) instead of a staging buffer
         d8 = (lambda name, stage, n: S[name][i][r] if keep8 else stage[: Mr * n].view(Mr, n))
         e1 = self._emit_to(k1, d8("y1_8", ws_q_a[ln], Dm), 0) if self.fp8 else None
+        lean = self._fp8_lean(Dm, T, H)
         fuse = self._ln_fused_fwd(Mr, Dm)
         if not (fuse and (self._ln_fuse_mask & 2) and i > 0):   # (fused: the previous block's fc2 epilogue has already left norm1(x_in) in y1 and its statistics)
-            ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, st=st)
+            ops.layernorm_fwd(x_in, P(pre + "norm1.weight"), P(pre + "norm1.bias"), y1, stt[0], stt[1], emit=e1, skip_out=lean and e1 is not None, st=st)
         self._mm(y1, pre + "attn.qkv.weight", qkv, bias=P(pre + "attn.qkv.bias"), st=st, lane=ln, site=k1, a8=e1[0] if e1 else None)
         # (fp8 mode) attention leaves its output as fp8 bytes for attn.proj (q_a: y1 has been consumed by the qkv GEMM, y2 comes after proj)
         eo = self._emit_to(ko, d8("o_8", ws_q_a[ln], Dm), 0) if (self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H)) else None
@@ -650,14 +661,14 @@ class Engine:
             self._mm(o, pre + "attn.proj.weight", x_mid, bias=P(pre + "attn.proj.bias"), epilogue=EPI_RESID, resid=x_in, st=st, lane=int(b0 > 0), site=ko,
                      a8=eo[0] if eo else None)
             e2 = self._emit_to(k2, d8("y2_8", ws_q_a[ln], Dm), 0) if self.fp8 else None
-            ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], emit=e2, st=st)
+            ops.layernorm_fwd(x_mid, P(pre + "norm2.weight"), P(pre + "norm2.bias"), y2, stt[2], stt[3], emit=e2, skip_out=lean and e2 is not None, st=st)
         # (fp8 mode) kh = the site of fc2's A operand: h leaves the fc1 epilogue as bf16 AND as fp8 bytes
         h8 = d8("h_8", self.ws.q_b[ln], 4 * Dm) if self.fp8 else None
         eh = self._emit_to(kh, h8, 0) if self.fp8 else None
         self._mm(y2, pre + "mlp.fc1.weight", h, bias=P(pre + "mlp.fc1.bias"), epilogue=EPI_GELU, aux=pre_a, st=st, lane=ln, site=k2, a8=e2[0] if e2 else None, emit_site=kh,
-                 emit_dst=h8)
+                 emit_dst=h8, skip_out=lean)
         if keep8:   # which of the block's kept copies this pass really wrote (none without amax history; o only from the LDS-resident attention kernels)
-            self._fp8_kept[(id(S), i)] = dict(y1=e1 is not None, o=eo is not None, y2=e2 is not None, h=eh is not None)
+            self._fp8_kept[(id(S), i)] = dict(y1=e1 is not None, o=eo is not None, y2=e2 is not None, h=eh is not None, lean=lean)
         if fuse and (self._ln_fuse_mask & 2) and i + 1 < S["xm"].shape[0]:   # x_out = x_mid + fc2(h) and the NEXT block's y1 = norm1(x_out) in one kernel
             nxt = pre[: pre.rstrip(".").rfind(".") + 1] + f"{i + 1}."
             sn = [a[r] for a in S["st"][i + 1][:2]]
@@ -719,6 +730,8 @@ class Engine:
         # fp8 weight gradients: the fp8 copies of the gradient tensors live in twins of the rotating bf16 buffers (same indices, same lifetimes: the guards
         # on the bf16 buffers cover them) instead of two staging buffers that the next kernel of the chain overwrites
         tw = self.fp8 and self.fp8_dw and lps8 is not None
+        kept = self._fp8_kept.get((id(S), i), {}) if tw else {}
+        lean = bool(kept.get("lean"))   # the forward pass left no bf16 y1 / y2 / h (_fp8_lean): this pass writes no bf16 dpre / dqkv either
         dpre8 = ws.t4_8[self._tog][: M * 4 * Dm].view(M, 4 * Dm) if tw else None
         ed = (self._emit_to(kd, dpre8, 1) if tw else self._emit(kd, ws.q_b[0], M, 4 * Dm, 1)) if self.fp8 else None
         if tw and kc is None and ws.fp8_hist and self._fp8_fuse:
@@ -733,9 +746,9 @@ class Engine:
         carried = ops._timer is None and not os.environ.get("CSMAE_DW_MAIN")
         ev1 = self._event() if (carried and mode == "half") else None
         with (ops.launch_done(ev1, st) if ev1 is not None else contextlib.nullcontext()):
-            self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd, emit_dst=dpre8)
+            self._mm(cur, pre + "mlp.fc2.weight", dpre, trans_b=True, epilogue=EPI_DGELU, aux=S["pre"][i], st=st, site=kc, a8=c8, emit_site=kd, emit_dst=dpre8,
+                     skip_out=lean)
         slots = self._dw_slots_ed[0 if S is ws.enc else 1] if self._dw_slots_ed else None
-        kept = self._fp8_kept.get((id(S), i), {}) if tw else {}
         fs = self._fp8_blk.get((id(S), i)) if tw else None   # the block's forward sites (y1, o, y2, h)
         dq = ws.fp8_dq if self.fp8 else None
         ok8 = tw and fs is not None and Dm >= 256 and Dm % 16 == 0
@@ -743,6 +756,8 @@ class Engine:
             g8 = None
             if ok8 and c8 is not None and ed is not None and kept.get("h") and kept.get("y2"):
                 g8 = [(c8, dq[kc:kc + 1], S["h_8"][i], dq[fs[3]:fs[3] + 1], pre + "mlp.fc2"), (ed[0], dq[kd:kd + 1], S["y2_8"][i], dq[fs[2]:fs[2] + 1], pre + "mlp.fc1")]
+            if lean and g8 is None:
+                raise RuntimeError("csmae_hip fp8: the forward pass kept no bf16 activations (Engine._fp8_lean) but the weight gradients of fc2 / fc1 cannot take the fp8 path")
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1")], slots, ready=ev1, items8=g8)
         elif mode == "none":
             self._dw(dpre, y2, pre + "mlp.fc1")
@@ -776,7 +791,7 @@ class Engine:
         if self.fp8 and self._fp8_fuse_attn and ops.attn_resident(ops.BF16, T, Dm // H):
             eq = self._emit_to(kq, ws.t3_8[self._tog][: M * 3 * Dm].view(M, 3 * Dm), 1) if tw else self._emit(kq, ws.q_b[0], M, 3 * Dm, 1)
         with (ops.launch_done(ev2, st) if ev2 is not None else contextlib.nullcontext()):
-            ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, emit=eq, st=st)
+            ops.attn_bwd(S["qkv"][i], S["o"][i], t1, lse, dqkv, B2, T, H, Dm // H, emit=eq, skip_out=lean and eq is not None, st=st)
         if mode == "block":
             self._dw_group([(cur, S["h"][i], pre + "mlp.fc2"), (dpre, y2, pre + "mlp.fc1"),
                             (nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2)
@@ -784,6 +799,8 @@ class Engine:
             g8 = None
             if ok8 and en is not None and eq is not None and kept.get("o") and kept.get("y1"):
                 g8 = [(en[0], dq[kn:kn + 1], S["o_8"][i], dq[fs[1]:fs[1] + 1], pre + "attn.proj"), (eq[0], dq[kq:kq + 1], S["y1_8"][i], dq[fs[0]:fs[0] + 1], pre + "attn.qkv")]
+            if lean and g8 is None:
+                raise RuntimeError("csmae_hip fp8: the forward pass kept no bf16 activations (Engine._fp8_lean) but the weight gradients of attn.proj / attn.qkv cannot take the fp8 path")
             self._dw_group([(nxt, S["o"][i], pre + "attn.proj"), (dqkv, y1, pre + "attn.qkv")], slots, ready=ev2, items8=g8)
         else:
             self._dw(dqkv, y1, pre + "attn.qkv")

@@ -242,9 +242,11 @@ def fp8_weights(desc, p, w8, w8t, amax, dq, st=None):
     check(load().csmae_fp8_weights(desc.shape[0], _p(desc), _p(p), _p(w8), _p(w8t), _p(amax), _p(dq), st if st is not None else stream()), "csmae_fp8_weights")
 
 
-def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI_NONE, aux=None, resid=None, emit=None, st=None):
+def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI_NONE, aux=None, resid=None, emit=None, skip_out=False, st=None):
     """out[M,N] = dq_a * dq_b * a8[M,K] b8[N,K]^T (+ epilogue): both operands K-contiguous fp8 bytes (uint8 tensors).
-    emit = (q_out uint8 [M,N], fmt, amax_prev [64], amax_next [64], dq [1]): the epilogue also writes `out` as fp8 bytes for the next GEMM."""
+    emit = (q_out uint8 [M,N], fmt, amax_prev [64], amax_next [64], dq [1]): the epilogue also writes `out` as fp8 bytes for the next GEMM.
+    skip_out (with emit): `out` only names shape / dtype / row stride — the kernel writes the fp8 copy (and the gelu' codes) and not the bf16 tensor."""
+    assert not skip_out or emit is not None
     M, K = a8.shape
     N = b8.shape[0]
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == K and out.shape == (M, N)
@@ -253,7 +255,7 @@ def gemm_fp8(a8, b8, out, dq_a, dq_b, *, a_fmt=FP8_E4M3, bias=None, epilogue=EPI
         epilogue = {EPI_GELU: 6, EPI_DGELU: 7}[epilogue]
     if _timer is not None:
         _timer.begin()
-    check(load().csmae_gemm_fp8(a_fmt, M, N, K, _p(a8), a8.stride(0), _p(b8), b8.stride(0), _p(out), out.stride(0), dt(out), _p(bias), epilogue,
+    check(load().csmae_gemm_fp8(a_fmt, M, N, K, _p(a8), a8.stride(0), _p(b8), b8.stride(0), None if skip_out else _p(out), out.stride(0), dt(out), _p(bias), epilogue,
                                 _p(aux), aux.stride(0) if aux is not None else 0, _p(resid), resid.stride(0) if resid is not None else 0,
                                 _p(dq_a), _p(dq_b), _p(emit[0]) if emit else None, emit[0].stride(0) if emit else 0, emit[1] if emit else 0,
                                 _p(emit[2]) if emit else None, _p(emit[3]) if emit else None, _p(emit[4]) if emit else None,
@@ -336,11 +338,13 @@ def attn_fwd(qkv, out, lse, B, T, H, hd, emit=None, st=None):
         check(load().csmae_attn_fwd_q(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(lse), *_emit_args(emit), st if st is not None else stream()), "csmae_attn_fwd_q")
 
 
-def attn_bwd(qkv, out, dout, lse, dqkv, B, T, H, hd, emit=None, st=None):
+def attn_bwd(qkv, out, dout, lse, dqkv, B, T, H, hd, emit=None, skip_out=False, st=None):
+    """skip_out (with emit): only the fp8 copy of dqkv is written."""
+    assert not skip_out or emit is not None
     if emit is None:
         check(load().csmae_attn_bwd(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), st if st is not None else stream()), "csmae_attn_bwd")
     else:
-        check(load().csmae_attn_bwd_q(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), *_emit_args(emit), st if st is not None else stream()),
+        check(load().csmae_attn_bwd_q(dt(qkv), B, T, H, hd, _p(qkv), _p(out), _p(dout), _p(lse), None if skip_out else _p(dqkv), *_emit_args(emit), st if st is not None else stream()),
               "csmae_attn_bwd_q")
 
 
@@ -351,9 +355,11 @@ def _emit_args(emit):
     return _p(emit[0]), emit[1], _p(emit[2]), _p(emit[3]), _p(emit[4])
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, y32=None, eps=1e-6, emit=None, st=None):
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, y32=None, eps=1e-6, emit=None, skip_out=False, st=None):
+    """skip_out (with emit): only the fp8 copy of y (and the row statistics) is written."""
     M, D = x.shape
-    check(load().csmae_layernorm_fwd(dt(x), dt(y), M, D, _p(x), _p(gamma), _p(beta), eps, _p(y), _p(y32), _p(mean), _p(rstd), *_emit_args(emit),
+    assert not skip_out or emit is not None
+    check(load().csmae_layernorm_fwd(dt(x), dt(y), M, D, _p(x), _p(gamma), _p(beta), eps, None if skip_out else _p(y), _p(y32), _p(mean), _p(rstd), *_emit_args(emit),
                                      st if st is not None else stream()), "csmae_layernorm_fwd")
 
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
 // four gradient values of dqkv: bf16, and — EMIT — the fp8 byte copy at the same element offset (see attn_fwd_bf16)
 template <bool EMIT>
 __device__ __forceinline__ void st4_dqkv(bf16_t* dqkv, long long at, f4_t v, const Fp8Emit& em, float qs, float qmax, float& qseen) {
-  st4<bf16_t>(dqkv + at, v);
+  if (!EMIT || dqkv) st4<bf16_t>(dqkv + at, v);   // (EMIT with dqkv == null: the fp8 copy is the only output — fp8 mode, where nothing reads the bf16 tensor)
   if (EMIT) *reinterpret_cast<unsigned*>(em.q + at) = fp8_pack4(round4<bf16_t>(v), qs, qmax, em.fmt, qseen);
 }
 template <int HD, int NKF, bool EMIT = false>
@@ -1020,6 +1020,7 @@ static int attn_bwd_impl(int dtype, long long B, int T, int H, int hd, const voi
   const int D = H * hd;
   int rc = check_common("csmae_attn_bwd", B, T, H, D, hd);
   if (rc) return rc;
+  CSMAE_REQUIRE(dqkv || em, "csmae_attn_bwd: dqkv is null (allowed in csmae_attn_bwd_q only: the fp8 copy is then the only output)");
   hipStream_t st = (hipStream_t)stream;
   const float scale = 1.0f / sqrtf((float)hd);
   const int BH = (int)(B * H);

@@ -859,6 +859,8 @@ extern "C" int csmae_gemm_fp8(int a_fmt, long long M, long long N, long long K, 
                               const void* resid, long long ldr, const float* dq_a, const float* dq_b, void* q_out, long long ldq, int q_fmt,
                               const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream) {
   CSMAE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 4 == 0 && ldc % 4 == 0, "csmae_gemm_fp8: bad geometry M=%lld N=%lld K=%lld", M, N, K);
+  CSMAE_REQUIRE(A && B && (C || (q_out && c_dtype == CSMAE_BF16 && (epilogue == EPI_DGELU || epilogue == 6 || epilogue == 7 || epilogue == EPI_NONE))),
+                "csmae_gemm_fp8: null operand (C may be null only with the fused fp8 copy and a non-residual epilogue: then that copy is the product's only output)");
   CSMAE_REQUIRE(a_fmt == 0 || a_fmt == 1, "csmae_gemm_fp8: a_fmt 0 (e4m3) or 1 (e5m2)");
   const int q8 = (epilogue == 6 || epilogue == 7);
   if (q8) epilogue = epilogue == 6 ? EPI_GELU : EPI_DGELU;

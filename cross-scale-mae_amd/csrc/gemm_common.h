@@ -346,7 +346,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
           }
         }
       }
-      if (gm < p.M && !(GEMM_EPI_ABL & 4)) {
+      if (gm < p.M && C != nullptr && !(GEMM_EPI_ABL & 4)) {   // (C == null: the fused fp8 copy is the only output — csmae_gemm_fp8 in fp8 mode, where nothing reads the bf16 tensor)
         if (ok1) {
           if (EPI == EPI_GELU && !p.aux_q8) *reinterpret_cast<uint4*>(X + (long long)gm * p.ldaux + gn) = make_uint4(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]), pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
           *reinterpret_cast<uint4*>(C + (long long)gm * p.ldc + gn) = make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(long long M, int D, const T
       if (c < nv) {
         f4_t gm = *reinterpret_cast<const f4_t*>(gamma + c * 4), bt = *reinterpret_cast<const f4_t*>(beta + c * 4);
         f4_t o = (v[i] - mu) * rs * gm + bt;
-        st4<TO>(y + row * D + c * 4, o);
+        if (y) st4<TO>(y + row * D + c * 4, o);   // (y == null: only the fp8 copy leaves — fp8 mode, where nothing reads the bf16 output)
         if (y32) *reinterpret_cast<f4_t*>(y32 + row * D + c * 4) = o;
         if (em.q) *reinterpret_cast<unsigned*>(em.q + row * D + c * 4) = fp8_pack4(o, qscale, qmax, em.fmt, qseen);
       }
@@ -273,6 +273,7 @@ extern "C" int csmae_layernorm_fwd(int x_dtype, int out_dtype, long long M, int 
                                    float* q_amax_next, float* q_dq, void* stream) {
   CSMAE_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "csmae_layernorm_fwd: need 0 < D <= 2048, D %% 4 == 0 (D=%d)", D);
   if (int rc = fp8_emit_check("csmae_layernorm_fwd", q_out, q_fmt, q_amax_prev, q_amax_next, q_dq)) return rc;
+  CSMAE_REQUIRE(x && mean && rstd && (y || q_out), "csmae_layernorm_fwd: null argument (y may be null only when the fp8 copy is asked for)");
   const Fp8Emit em{(unsigned char*)q_out, q_amax_prev, q_amax_next, q_dq, q_fmt};
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == CSMAE_F32 && out_dtype == CSMAE_BF16) ln_fwd_launch<float, bf16_t>(M, D, x, gamma, beta, eps, y, y32, mean, rstd, em, st);

@@ -113,7 +113,9 @@ int csmae_gemm_dw_group_fp8(int count, long long K, const void* const* dY, const
  * q = fp8(x * FMAX / amax) (fmt 0 = e4m3, 1 = e5m2; transpose = 1 writes dst[c][r], the mirror of a weight the dX products read) and
  * the de-quantisation factor dq = amax / FMAX; with amax_next the amax passed in is the previous step's (one pass over the tensor,
  * out-of-range values saturate) and this step's is recorded for the next.  csmae_gemm_fp8: C[M,N] = dq_a * dq_b * sum_k A8(m,k) B8(n,k) with both operands
- * K-contiguous fp8 bytes (A in a_fmt, B e4m3), fp32 accumulation (v_mfma_scale_f32_16x16x128_f8f6f4), epilogues of csmae_gemm. */
+ * K-contiguous fp8 bytes (A in a_fmt, B e4m3), fp32 accumulation (v_mfma_scale_f32_16x16x128_f8f6f4), epilogues of csmae_gemm.  With the fused fp8 copy
+ * (q_out) and an epilogue without a residual, C may be NULL: the copy (and the gelu' codes) is then the product's only output — fp8 mode's steady state,
+ * where the next product, the weight gradients and the bias gradients all read the fp8 bytes. */
 int csmae_fp8_amax(int in_dtype, long long rows, int cols, const void* src, long long ld, float* amax, void* stream);
 int csmae_fp8_quantize(int in_dtype, int fmt, int transpose, long long rows, int cols, const void* src, long long ld, void* dst,
                        long long ldd, const float* amax, float* dq, float* amax_next /* nullable: delayed scaling, += max|src| */, void* stream);
@@ -138,7 +140,8 @@ int csmae_attn_bwd(int dtype, long long B, int T, int H, int hd, const void* qkv
  * attn.proj forward reads `out` (q_fmt 0: e4m3), attn.qkv's backward reads dqkv (q_fmt 1: e5m2) — quantised from the rounded bf16 values
  * with FMAX / max(q_amax_prev[64]) (the tensor's amax one step earlier: delayed scaling, conventions of csmae_gemm_fp8); q_amax_next[64]
  * receives partial maxima of |x|, q_dq[0] the de-quantisation factor.  bf16 shapes of the LDS-resident kernels only: csmae_attn_resident().
- * Same reference expression (timm Attention inside Block, models_mae/MAE_ViT_Baseline.py:160-188); replaces a csmae_fp8_quantize pass. */
+ * Same reference expression (timm Attention inside Block, models_mae/MAE_ViT_Baseline.py:160-188); replaces a csmae_fp8_quantize pass.
+ * csmae_attn_bwd_q: dqkv may be NULL — the fp8 copy is then the only output (no reader of the bf16 gradient in fp8 mode's steady state). */
 int csmae_attn_resident(int dtype, int T, int hd);
 int csmae_attn_fwd_q(int dtype, long long B, int T, int H, int hd, const void* qkv, void* out, float* lse, void* q_out, int q_fmt,
                      const float* q_amax_prev, float* q_amax_next, float* q_dq, void* stream);
@@ -152,7 +155,8 @@ int csmae_attn_bwd_q(int dtype, long long B, int T, int H, int hd, const void* q
  * block; null -> atomics).  dgamma == NULL with a workspace: the partial rows (min(ceil(M/4), 1024, partial_elems / 2D) of them) are
  * left there for csmae_ln_param_reduce, which folds a whole batch of LayerNorms in one launch off the critical path.
  * q_out (nullable; fp8 mode, delayed scaling): the output that feeds the next GEMM (y / dx_out) also leaves as fp8 bytes [M][D] in q_fmt,
- * scaled with q_amax_prev (64 partial maxima), the new amax folded into q_amax_next (64 slots), the de-quantisation factor in q_dq. */
+ * scaled with q_amax_prev (64 partial maxima), the new amax folded into q_amax_next (64 slots), the de-quantisation factor in q_dq.
+ * fwd with q_out: y may be NULL — only the fp8 copy (and mean / rstd) is written (fp8 mode's steady state: every reader of y takes the fp8 bytes). */
 int csmae_layernorm_fwd(int x_dtype, int out_dtype, long long M, int D, const void* x, const float* gamma, const float* beta, float eps,
                         void* y, float* y32, float* mean, float* rstd, void* q_out, int q_fmt, const float* q_amax_prev,
                         float* q_amax_next, float* q_dq, void* stream);

@@ -253,7 +253,7 @@ def test_gemm_fp8_vs_fp32_on_the_quantised_operands(ops, a_fmt):
     """csmae_gemm_fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation) against an fp32 matmul of the DE-QUANTISED operands: the
     products are exact in fp32, so the two agree up to the order of the additions.  Asymmetric operands (a transposed or permuted
     fragment layout would not pass), ragged M / N, K with a partial last K step, every epilogue the step uses."""
-    from csmae_hip import EPI_DGELU, EPI_GELU, EPI_RESID
+    from csmae_hip import EPI_DGELU, EPI_GELU, EPI_NONE, EPI_RESID
     adt = torch.float8_e4m3fn if a_fmt == 0 else torch.float8_e5m2
     for M, N, K in ((256, 256, 128), (512, 768, 1280), (300, 520, 400), (1000, 264, 2048)):
         a = rnd(M, K, seed=80) * (1.0 + torch.arange(K) / K)[None, :] + torch.arange(M)[:, None] / M
@@ -297,6 +297,15 @@ def test_gemm_fp8_vs_fp32_on_the_quantised_operands(ops, a_fmt):
         want = out2.float().cpu().clamp(-float(prev.max()), float(prev.max()))
         tol = (0.0625 if a_fmt == 0 else 0.125) * want.abs() + float(prev.max()) * (2.0 ** -9 if a_fmt == 0 else 2.0 ** -16) + 8e-3 * want.abs()
         assert bool(((deq - want).abs() <= tol).all()), float(((deq - want).abs() - tol).max())
+        # ... and with the bf16 output skipped (fp8 mode's steady state: every reader takes the fp8 bytes): the same copy, `out` untouched
+        for epi, ax in ((EPI_DGELU, aux), (EPI_NONE, None)):
+            q_ref, q3, keep = torch.zeros_like(q), torch.zeros_like(q), torch.full_like(out2, 7.0)
+            ops.gemm_fp8(a8, w8, out2, dqa, dqw, a_fmt=a_fmt, epilogue=epi, aux=ax, emit=(q_ref, efmt, prev, nxt, dqo))
+            nxt.zero_()
+            ops.gemm_fp8(a8, w8, keep, dqa, dqw, a_fmt=a_fmt, epilogue=epi, aux=ax, emit=(q3, efmt, prev, nxt, dqo), skip_out=True)
+            assert torch.equal(q3, q_ref) and bool((keep == 7.0).all()) and abs(float(nxt.max()) - float(out2.float().abs().max())) <= 8e-3 * float(nxt.max())
+        with pytest.raises(RuntimeError):   # (a residual epilogue's bf16 output is the residual stream: it cannot be skipped)
+            ops.gemm_fp8(a8, w8, keep, dqa, dqw, a_fmt=a_fmt, epilogue=EPI_RESID, resid=dev(resid), emit=(q3, efmt, prev, nxt, dqo), skip_out=True)
 
 
 def test_fp8_weights_batched_matches_per_weight_quantisation(ops):
@@ -438,6 +447,11 @@ def test_attention_emits_the_fp8_copies_of_a_separate_quantisation_pass(ops, geo
         assert torch.equal(q, want_q), which
         assert float(nxt.max()) == float(ref.float().abs().max()) == float(want_next.max()), which
         assert float(dq) == float(want_dq), which
+        if which == "bwd":   # fp8 mode's steady state: no reader of the bf16 gradient — only the fp8 copy is written, the same bytes
+            q2, keep = torch.zeros_like(q), torch.full_like(ref, 7.0)
+            nxt.zero_()
+            ops.attn_bwd(qkv, out0, dout, lse, keep, B, T, H, hd, emit=(q2, fmt, prev, nxt, dq), skip_out=True)
+            assert torch.equal(q2, want_q) and bool((keep == 7.0).all()) and float(nxt.max()) == float(want_next.max())
 
 
 # ------------------------------------------------------------------------------------------------ norms
@@ -538,6 +552,9 @@ def test_layernorm_emits_fp8_copy(ops, fmt):
     want = y.float().cpu().clamp(-am, am)
     tol = (0.0625 if fmt == 0 else 0.125) * want.abs() + am * (2.0 ** -9 if fmt == 0 else 2.0 ** -16) + 8e-3 * want.abs()
     assert bool(((deq - want).abs() <= tol).all())
+    q2, keep, mean2, rstd2 = torch.zeros_like(q), torch.full_like(y, 7.0), torch.empty_like(mean), torch.empty_like(rstd)   # only the fp8 copy (fp8 mode's steady state)
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), keep, mean2, rstd2, emit=(q2, fmt, prev, nxt, dq), skip_out=True)
+    assert torch.equal(q2, q) and bool((keep == 7.0).all()) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
     dy, dres = rnd(M, D, seed=33).to(torch.bfloat16), rnd(M, D, seed=34).to(torch.bfloat16)
     dx, dx2 = torch.empty(M, D, device="cuda", dtype=torch.bfloat16), torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
     part = torch.empty(1024 * 2 * D, device="cuda")
