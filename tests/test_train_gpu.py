@@ -128,7 +128,9 @@ def test_data_parallel_world1_rccl_matches_plain():
             m = models_mae.MAE_ViT_MsLdCeCd(**micro, input_size=64, predictor_hidden_size=128).cuda()
             m.compute_dtype = torch.bfloat16
             w = m if mode == "plain" else DataParallel(m, comm_dtype=None if mode == "fp32" else "auto", force_collectives=True)
-            opt = FusedAdamW(add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+            # (the wrapped runs step the way bench.py / main_pretrain.py do: the optimizer on its own stream behind the exchange's join, the next
+            # forward pass ordering its layers behind the launch that steps their weights)
+            opt = FusedAdamW(add_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95), overlap=mode != "plain")
             gg = torch.Generator().manual_seed(9)
             for step in range(3):
                 m._test_draws = dict(noise=[torch.rand(4, 16, generator=gg), torch.rand(4, 16, generator=gg)], box=(7, 2, 45, 48))
