@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Attention fwd/bwd micro-benchmark on the step's shapes (decoder: B=256,T=197,H=16,hd=32; encoder: B=256,T=50,H=12,hd=64)."""
+"""Attention fwd/bwd micro-benchmark on the step's shapes (decoder: B=256,T=197,H=16,hd=32; encoder: B=256,T=50,H=12,hd=64; --huge14: the ViT-H/14 preset's)."""
 import os
 import sys
 
@@ -9,7 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cross-scale-mae_amd"))
 from csmae_hip import ops  # noqa: E402
 
-for name, B, T, H, hd in [("dec", 256, 197, 16, 32), ("enc", 256, 50, 12, 64)]:
+SHAPES = [("dec", 256, 197, 16, 32), ("enc", 256, 50, 12, 64)]
+if "--huge14" in sys.argv:   # ViT-H/14 at 256 per GPU (BASELINE.json configs[4]): encoder 65 tokens x 16 heads of 80, decoder 257 x 16 x 32
+    sys.argv.remove("--huge14")
+    SHAPES = [("h14 enc", 512, 65, 16, 80), ("h14 dec", 512, 257, 16, 32)]
+for name, B, T, H, hd in SHAPES:
     D = H * hd
     qkv = torch.randn(B * T, 3 * D, device="cuda").to(torch.bfloat16)
     dout = torch.randn(B * T, D, device="cuda").to(torch.bfloat16)
