@@ -240,14 +240,23 @@ __device__ __forceinline__ float fp8_emit_scale(const Fp8Emit& e, int lane, floa
   if (blockIdx.x == 0 && threadIdx.x == 0) e.dq[0] = am > 0.f ? am / qmax : 1.f;
   return am > 0.f ? qmax / am : 1.f;
 }
+// |x| as an unsigned integer: non-negative floats order like their bit patterns, +Inf (0x7f800000) sorts above every finite value and the NaN patterns above
+// +Inf — so the running maximum of a tensor WITH its non-finite values is two integer ops per element (v_and + a share of v_max3_u32) instead of a compare, a
+// select and a float max (the emitting epilogues are VALU-bound: csmae_gemm_fp8's GELU epilogue spends ~25 ops per element)
+__device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
+__device__ __forceinline__ float amax_of_bits(unsigned s) { return s > 0x7f800000u ? INFINITY : __uint_as_float(s); }   // (NaN records +Inf, like Inf)
 __device__ __forceinline__ unsigned fp8_pack4(f4_t v, float scale, float qmax, int fmt, float& seen) {
   int p = 0;
+  // non-finite values are not hidden: NaN passes through the clamp, NaN / Inf record an amax of +Inf (next step: scale 0 x Inf = NaN -> the loss gate trips)
+  const unsigned m = max(umax3(abs_bits(v[0]), abs_bits(v[1]), abs_bits(v[2])), abs_bits(v[3]));
+  seen = fmaxf(seen, amax_of_bits(m));
+  const f4_t q = v * scale;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {   // non-finite values are not hidden: NaN passes through the clamp, NaN / Inf record an amax of +Inf (next step: scale 0 x Inf = NaN -> the loss gate trips)
-    const float a = fabsf(v[k]);
-    seen = fmaxf(seen, a == a ? a : INFINITY);
-    const float q = v[k] * scale;
-    v[k] = q != q ? q : fminf(fmaxf(q, -qmax), qmax);
+  for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(q[k], -qmax, qmax);
+  if (__builtin_amdgcn_ballot_w64(m >= 0x7f800000u) != 0ull) {   // (rare, wave-uniform branch: an Inf or a NaN somewhere in the wave — v_med3 would turn a NaN, also the NaN of Inf x 0, into -qmax)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = q[k] != q[k] ? q[k] : v[k];
   }
   if (fmt == 0) { p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true); }
   else { p = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], p, false); p = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], p, true); }

@@ -242,6 +242,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
   const bool emit = p.q_out != nullptr;
   const float qmax = p.q_fmt == 0 ? 448.0f : 57344.0f;
   float qscale = 1.f, qseen = 0.f;
+  unsigned qbits = 0u;   // (the running amax as a bit pattern, see the emit block)
   if (emit) {
     const float am = wave_max64(p.q_amax_prev[lane]);
     qscale = am > 0.f ? qmax / am : 1.f;
@@ -301,11 +302,17 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
       }
       if (emit && gm < p.M && ok0) {   // the fp8 copy of this row segment (8 or 4 columns)
         f4_t q0 = o0 * qscale, q1 = o1 * qscale;
+        // the running maximum on bit patterns (common.h abs_bits: a NaN / Inf makes the recorded amax +Inf — the next step's scale is 0 x Inf = NaN, the loss
+        // gate trips); the clamp as one v_med3 per element, NaN put back on the rare path (NaN is not clamped away)
+        unsigned mb = umax3(abs_bits(o0[0]), abs_bits(o0[1]), umax3(abs_bits(o0[2]), abs_bits(o0[3]), 0u));
+        if (ok1) mb = umax3(mb, umax3(abs_bits(o1[0]), abs_bits(o1[1]), abs_bits(o1[2])), abs_bits(o1[3]));
+        qbits = max(qbits, mb);
+        const f4_t u0 = q0, u1 = q1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float a0 = fabsf(o0[k]), a1 = ok1 ? fabsf(o1[k]) : 0.f;
-          qseen = fmaxf(qseen, fmaxf(a0 == a0 ? a0 : INFINITY, a1 == a1 ? a1 : INFINITY));   // (a NaN / Inf makes the recorded amax +Inf: the next step's scale is 0 x Inf = NaN, the loss gate trips)
-          q0[k] = q0[k] != q0[k] ? q0[k] : fminf(fmaxf(q0[k], -qmax), qmax); q1[k] = q1[k] != q1[k] ? q1[k] : fminf(fmaxf(q1[k], -qmax), qmax);   // NaN is not clamped away
+        for (int k = 0; k < 4; ++k) { q0[k] = __builtin_amdgcn_fmed3f(u0[k], -qmax, qmax); q1[k] = __builtin_amdgcn_fmed3f(u1[k], -qmax, qmax); }
+        if (__builtin_amdgcn_ballot_w64(mb >= 0x7f800000u) != 0ull) {   // (wave-uniform: skipped as a whole when every value is finite)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { q0[k] = u0[k] != u0[k] ? u0[k] : q0[k]; q1[k] = u1[k] != u1[k] ? u1[k] : q1[k]; }
         }
         int w0 = 0, w1 = 0;
         if (p.q_fmt == 0) {
@@ -358,7 +365,7 @@ __device__ __forceinline__ void epilogue_rows_bf16x8(const GemmArgs& p, void* Cp
     }
   }
   if (emit) {   // this wave's share of the new amax: one atomic per wave, spread over the 64 slots
-    qseen = wave_max64(qseen);
+    qseen = wave_max64(amax_of_bits(qbits));
     if (lane == 0) amax_publish(p.q_amax_next + ((blockIdx.x * 8 + (threadIdx.x >> 6)) & 63), qseen);
   }
 }

@@ -304,6 +304,17 @@ def test_gemm_fp8_vs_fp32_on_the_quantised_operands(ops, a_fmt):
             nxt.zero_()
             ops.gemm_fp8(a8, w8, keep, dqa, dqw, a_fmt=a_fmt, epilogue=epi, aux=ax, emit=(q3, efmt, prev, nxt, dqo), skip_out=True)
             assert torch.equal(q3, q_ref) and bool((keep == 7.0).all()) and abs(float(nxt.max()) - float(out2.float().abs().max())) <= 8e-3 * float(nxt.max())
+        # non-finite values are not hidden by the copy: a NaN stays a NaN (it is not clamped to a finite code), an Inf saturates, both record an amax of +Inf
+        bad = dev(bias).clone(); bad[3] = float("nan"); bad[9] = float("inf"); bad[12] = float("-inf")
+        q_ok, q_bad = torch.zeros_like(q), torch.zeros_like(q)
+        ops.gemm_fp8(a8, w8, out2, dqa, dqw, a_fmt=a_fmt, bias=dev(bias), emit=(q_ok, efmt, prev, nxt, dqo))
+        nxt.zero_()
+        ops.gemm_fp8(a8, w8, out2, dqa, dqw, a_fmt=a_fmt, bias=bad, emit=(q_bad, efmt, prev, nxt, dqo))
+        fb = q_bad.view(edt).float()
+        assert bool(torch.isnan(fb[:, 3]).all()) and bool((fb[:, 9] == fmax).all()) and bool((fb[:, 12] == -fmax).all()) and float(nxt.max()) == float("inf")
+        keep_cols = [c for c in range(N) if c not in (3, 9, 12)]
+        assert torch.equal(q_bad[:, keep_cols], q_ok[:, keep_cols])
+        nxt.zero_()
         with pytest.raises(RuntimeError):   # (a residual epilogue's bf16 output is the residual stream: it cannot be skipped)
             ops.gemm_fp8(a8, w8, keep, dqa, dqw, a_fmt=a_fmt, epilogue=EPI_RESID, resid=dev(resid), emit=(q3, efmt, prev, nxt, dqo), skip_out=True)
 
@@ -552,6 +563,13 @@ def test_layernorm_emits_fp8_copy(ops, fmt):
     want = y.float().cpu().clamp(-am, am)
     tol = (0.0625 if fmt == 0 else 0.125) * want.abs() + am * (2.0 ** -9 if fmt == 0 else 2.0 ** -16) + 8e-3 * want.abs()
     assert bool(((deq - want).abs() <= tol).all())
+    xb = x.clone(); xb[5, 7] = float("nan"); xb[9, 1] = float("inf")   # a non-finite row: its copy is NaN (not a clamped finite code), the recorded amax +Inf
+    qb, nb = torch.zeros_like(q), torch.zeros(64, device="cuda")
+    ops.layernorm_fwd(dev(xb), dev(g), dev(b), y2, torch.empty_like(mean), torch.empty_like(rstd), emit=(qb, fmt, prev, nb, dq))
+    fbq = qb.view(edt).float()
+    assert bool(torch.isnan(fbq[5]).all()) and bool(torch.isnan(fbq[9]).all()) and float(nb.max()) == float("inf")
+    rows = [r for r in range(M) if r not in (5, 9)]
+    assert torch.equal(qb[rows], q[rows])
     q2, keep, mean2, rstd2 = torch.zeros_like(q), torch.full_like(y, 7.0), torch.empty_like(mean), torch.empty_like(rstd)   # only the fp8 copy (fp8 mode's steady state)
     ops.layernorm_fwd(dev(x), dev(g), dev(b), keep, mean2, rstd2, emit=(q2, fmt, prev, nxt, dq), skip_out=True)
     assert torch.equal(q2, q) and bool((keep == 7.0).all()) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
