@@ -185,6 +185,8 @@ class FusedAdamW(torch.optim.Optimizer):
         ov = self.overlap and flat.p.is_cuda and ops._timer is None and not os.environ.get("CSMAE_OPT_MAIN")
         self.join()                   # (a previous overlapped step nobody ordered behind: this one's launches must be; no-op otherwise)
         st, pending = None, None
+        if not ov:
+            flat.opt_pending = None   # (this step is ordered on the current stream: nothing for a forward pass to gate on)
         if ov:
             if self._ostream is None:
                 self._ostream = torch.cuda.Stream()
